@@ -1,0 +1,118 @@
+/*
+ * swimm_hip.h -- C-ABI of libswimm_hip.so, the MI355X (gfx950) search back-end.
+ *
+ * This is the drop-in boundary for the SWIMM search hot path: plain C types only, no HIP or
+ * torch types, loadable with dlopen()/dlsym() (swimm_amd/csrc/host/hip_loader.c) or ctypes
+ * (swimm_amd/hip_backend.py).  The reference has no plugin layer; its seam is the set of plain
+ * C search functions main() calls (swimm.c:66-119).  Each entry point below names the
+ * reference interface it replaces (file:line under /root/reference).
+ *
+ * Conventions that differ from the reference on purpose:
+ *   - every function returns an int status (0 = ok) instead of printf + exit(); the message is
+ *     available from swimm_hip_last_error() (thread-local);
+ *   - the database stays resident in HBM between searches (288 GB per GPU) instead of being
+ *     re-sent chunk by chunk on every offload (MICsearch.c:85-91);
+ *   - a missing GPU / missing library is an error, never a silent CPU fallback.
+ *
+ * Data layouts accepted are exactly the reference's own:
+ *   queries  : `a` = recoded residues (0..23) of all queries concatenated, `m` = lengths as
+ *              stored in `a` (even-padded or not), `a_disp` = offsets, ascending length
+ *              (load_query_sequences, sequences.c:223-423);
+ *   database : chunks from assemble_multiple_chunks_db (sequences.c:425-616): per chunk the
+ *              lane-interleaved bytes b (byte of group g, position j, lane k at
+ *              b_disp[g] + j*vl + k, pad code 24), group lengths n[], offsets b_disp[];
+ *              `vl` must divide 128.
+ *   scores   : int32 scores[q * score_stride + sorted_db_index]  (CPUsearch.c:548,
+ *              MICsearch.c:333-334 use score_stride = vect_sequences_db_count * vl).
+ */
+#ifndef SWIMM_HIP_H_INCLUDED
+#define SWIMM_HIP_H_INCLUDED
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWIMM_HIP_ABI_VERSION 1
+#define SWIMM_HIP_SUBMAT_BYTES 768 /* 24 rows x 32 cols int8, submat.h:4-6 */
+
+typedef struct swimm_hip_ctx swimm_hip_ctx; /* one per GPU; not thread-safe, one host thread per ctx */
+
+/* ABI version of the loaded library. */
+int swimm_hip_abi_version(void);
+
+/* Message of the last failing call made by the calling thread ("" if none). */
+const char *swimm_hip_last_error(void);
+
+/* Number of visible gfx950 devices (replaces the -x num_mics probe; 0 and an error string when
+ * no GPU is usable). */
+int swimm_hip_device_count(void);
+
+/* Per-device state: stream, scratch.  Replaces the per-MIC host thread prologue
+ * `#pragma offload_transfer ... ALLOC` (MICsearch.c:53-71). */
+int swimm_hip_create(int device, swimm_hip_ctx **out);
+
+/* Replaces the `... FREE` epilogue (MICsearch.c:340-346). */
+void swimm_hip_destroy(swimm_hip_ctx *ctx);
+
+/* Queries + substitution matrix + gap penalties, sent once (transfer X1, MICsearch.c:34-36 and
+ * 67-71: a, m, a_disp, submat, queryProfiles).  Requires 0 <= open_gap, extend_gap and
+ * open_gap + extend_gap <= 127 (the reference stores the sum in an int8 lane, CPUsearch.c:518). */
+int swimm_hip_set_queries(swimm_hip_ctx *ctx, const char *a, const uint16_t *m, const uint32_t *a_disp,
+                          uint32_t query_count, const char *submat, int open_gap, int extend_gap);
+
+/* One database chunk in the reference's chunk layout (transfer X2 "in" half, MICsearch.c:85-88:
+ * ptr_chunk_b / ptr_chunk_n / ptr_chunk_b_disp).  `first_group` is the chunk's offset in
+ * vector groups within the whole database (chunk_accum_vect_sequences_db_count,
+ * MICsearch.c:46-49), so that sorted index = (first_group + g) * vl + lane.  The chunk is
+ * re-tiled on the device and stays resident until swimm_hip_clear_db(). */
+int swimm_hip_add_chunk(swimm_hip_ctx *ctx, const char *b, uint64_t vD, const uint16_t *n,
+                        const uint32_t *b_disp, uint32_t group_count, uint32_t vl, uint64_t first_group);
+
+int swimm_hip_clear_db(swimm_hip_ctx *ctx);
+
+/* The search itself (kernels K2-K5 + score scatter X3, MICsearch.c:91-334; same result as
+ * cpu_search_avx2_sp, CPUsearch.c:482-967).  For every query q and every resident sequence
+ * writes the exact Gotoh local-alignment score to scores[q*score_stride + sorted_index];
+ * entries of sequences that are not resident on this device are left untouched.
+ * *work_time (seconds, may be NULL) brackets kernels + D2H like the reference's workTime. */
+int swimm_hip_search(swimm_hip_ctx *ctx, int32_t *scores, uint64_t score_stride, double *work_time);
+
+/* Same search, but only the first r rows of the reference's sorted listing per query come back
+ * (replaces sort_scores + print loop, utils.c:71-86 / swimm.c:151-160): order is score
+ * descending, ties by larger sorted index first.  top_scores / top_index are [query_count][r];
+ * rows beyond the number of resident sequences are filled with score -1, index -1.
+ * `n_valid` = number of real sequences in the whole database (indices >= n_valid are padding
+ * lanes and never reported). */
+int swimm_hip_search_topr(swimm_hip_ctx *ctx, uint32_t r, uint64_t n_valid, int32_t *top_scores,
+                          int64_t *top_index, double *work_time);
+
+/* Statistics of the last search on this ctx (all optional, pass NULL to skip):
+ * kernel_ms = device time of the DP kernels (HIP events), cells = DP cells computed including
+ * padding, promoted = (query, sequence) pairs recomputed in int32, launches = DP kernel launches. */
+int swimm_hip_last_stats(swimm_hip_ctx *ctx, double *kernel_ms, uint64_t *cells, uint64_t *promoted,
+                         uint32_t *launches);
+
+/* Tuning knobs (optional).  key: "rows_per_wave" (16/32), "max_waves" (1..16), "force_i32" (0/1),
+ * "wgs_per_cu" (0 = auto).  Unknown key -> error. */
+int swimm_hip_set_option(swimm_hip_ctx *ctx, const char *key, int value);
+
+/* Whole-call drop-in with the argument list of mic_search_knc_ap_multiple_chunks
+ * (MICsearch.h:35-38, called at swimm.c:88-90): shards the chunks statically over `num_gpus`
+ * devices (one host thread each), searches, scatters into `scores`
+ * (stride vect_sequences_db_count * vl) and writes *workTime.  `mic_threads` and
+ * `query_length_threshold` of the original are meaningless on a GPU and dropped; `vl` (the
+ * lane width the chunks were assembled with) is added.  Returns 0 or an error status. */
+int swimm_hip_search_chunks(const char *query_sequences, const uint16_t *query_sequences_lengths,
+                            uint32_t query_sequences_count, const uint32_t *query_disp,
+                            uint64_t vect_sequences_db_count, char **chunk_b, uint32_t chunk_count,
+                            const uint32_t *chunk_vect_sequences_db_count, uint16_t **chunk_n,
+                            uint32_t **chunk_b_disp, const uint64_t *chunk_vD, const char *submat,
+                            int open_gap, int extend_gap, int num_gpus, uint32_t vl, int32_t *scores,
+                            double *workTime);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWIMM_HIP_H_INCLUDED */

@@ -1,0 +1,61 @@
+// Internal interface between the C-ABI shim (swimm_hip.cpp) and the device code
+// (sw_kernels.hip).  Not installed; the public boundary is include/swimm_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace swimm {
+
+constexpr int kCodes = 25;        // residue codes 0..24 (24 = lane padding), sequences.h:17-18
+constexpr int kGroupSeqs = 128;   // sequences per device group: 64 lanes x 2 packed int16 halves
+constexpr int kChunkCols = 4;     // DB columns per pipeline step (one dword per sequence)
+constexpr int kMaxWaves = 16;     // waves per workgroup (1024 threads)
+
+// One device group = 128 consecutive sorted sequences, tiled [chunk][lane][A0..A3 B0..B3].
+struct GroupDesc {
+    const uint8_t *db;   // tiled residues of this group
+    uint32_t ncols;      // padded length, multiple of kChunkCols
+    uint32_t seq0;       // local score slot of lane 0 (half A); half B starts at seq0 + 64
+};
+
+// One unit of work for a workgroup's pipeline.
+struct Item {
+    uint32_t group;      // index into GroupDesc[]
+    uint32_t half;       // int32 mode only: 0 = sequences 0..63 of the group, 1 = 64..127
+    uint32_t out_slot;   // int32 mode only: results go to out[out_slot*64 + lane]
+    uint32_t pad_;
+    uint64_t bnd_off;    // first column of this item in the pass-boundary buffer
+};
+
+struct PipeParams {
+    const GroupDesc *groups;
+    const Item *items;
+    const uint32_t *wg_first;   // [n_wg + 1] item ranges
+    const uint32_t *wg_chunks;  // [n_wg] total column chunks per workgroup
+    const int16_t *prof;        // query profile prof[d * prof_stride + row]
+    uint32_t prof_stride;       // rows allocated per code (>= passes * W * T)
+    uint32_t r0;                // first query row of this pass
+    uint2 *bnd;                 // pass boundary rows (H,F per column per lane), updated in place
+    int first_pass, last_pass;
+    int32_t *out;               // packed mode: score row of this query; int32 mode: out32
+    int goe, ge;                // open+extend, extend
+};
+
+enum class Mode { PK16, I32 };
+
+size_t pipe_lds_bytes(int rows_per_wave, int waves);
+// registers / occupancy of one instantiation (for the host-side launch plan)
+hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, int *num_regs);
+hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, int n_wg, const PipeParams &p, hipStream_t s);
+
+// Re-tile one reference-layout chunk (sequences.c:506-526 byte interleave) into device groups.
+hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t vl_groups, uint32_t vl,
+                         const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled,
+                         hipStream_t s);
+
+// flags[i] = 1 if any of scores[i*64 .. i*64+63] >= 32767 (int16 tier saturated)
+hipError_t launch_flag_saturated(const int32_t *scores, uint64_t n, uint8_t *flags, hipStream_t s);
+// scores[slot*64 + lane] = 0 for the listed half-groups (before the int32 rerun's atomicMax)
+hipError_t launch_reset_halves(int32_t *scores, const uint32_t *half_slots, uint32_t count, hipStream_t s);
+
+}  // namespace swimm

@@ -1,0 +1,340 @@
+// sw_kernels.hip -- gfx950 (MI355X / CDNA4) device code of the SWIMM search hot path.
+//
+// What the reference computes (CPUsearch.c:605-668, MICsearch.c:163-210): for every
+// (query, database sequence) pair the Gotoh affine-gap local-alignment score
+//     H = max(0, Hdiag + S(q_i, d_j), E, F);  E = max(E - ge, H - goe);  F = max(F - ge, H - goe)
+// keeping only max H.  Inter-task SIMD: one vector lane owns one database sequence.
+//
+// How it is mapped here (not a translation of the SSE/AVX2/KNC loops):
+//   * one wavefront lane owns TWO database sequences, packed as 2 x int16 in every VGPR
+//     (v_pk_add_i16 clamp / v_pk_max_i16 / v_pk_sub_u16 clamp: the narrowest packed integer
+//     lane CDNA4 has -- there is no packed int8 VALU), so one wave aligns 128 sequences;
+//   * a workgroup is a systolic pipeline of W waves over the QUERY: wave k owns query rows
+//     [k*T, (k+1)*T) in registers (H and E per row), walks the database columns in chunks of
+//     4, and hands the bottom row (H, F per column) to wave k+1 through an LDS ring, one
+//     chunk behind.  Only when the query is longer than W*T rows does a boundary row go
+//     through HBM, once per pass (the "strip" traffic of SURVEY.md 8d with T_eff = W*T);
+//   * the substitution lookup is a query profile staged in LDS, prof[d][row] int16: one
+//     ds_read_b64 fetches the scores of 4 consecutive query rows for a lane's residue d.
+//     The 25 code rows sit 8 bytes (mod 256) apart so the 25 possible addresses of a
+//     32-lane group fall on 25 different bank pairs: no bank conflicts whatever the residues;
+//   * each workgroup processes a host-built list of groups as ONE continuous column stream,
+//     so the pipeline fills and drains once per launch, not once per group;
+//   * saturation (lane best == 32767) is detected afterwards and those half-groups are re-run
+//     by the int32 instantiation of the same kernel (the reference's int8 -> int16 -> int32
+//     ladder, CPUsearch.c:678-957, with int16 as the first rung).
+//
+// E and F are kept clamped at >= 0.  That is exact: H already has a 0 floor, so replacing E by
+// max(E, 0) (and F likewise) never changes any H, and max(0, max(E,0) - ge, H - goe) equals
+// max(0, E - ge, H - goe) for ge >= 0.  It buys unsigned-saturating subtracts (no separate
+// max with 0) in the packed path.
+#include "sw_kernels.h"
+
+namespace swimm {
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+
+// ---- cell arithmetic, packed 2 x int16 ---------------------------------------------------
+struct OpsPK {
+    typedef v2s V;
+    static __device__ __forceinline__ V zero() { return (V)(0); }
+    static __device__ __forceinline__ V splat(int x) { return (V)((short)x); }
+    static __device__ __forceinline__ V from_bits(uint32_t x) { return as_v2s(x); }
+    static __device__ __forceinline__ uint32_t bits(V x) { return as_u32(x); }
+    static __device__ __forceinline__ V adds(V a, V b) { return __builtin_elementwise_add_sat(a, b); }
+    static __device__ __forceinline__ V vmax(V a, V b) { return __builtin_elementwise_max(a, b); }
+    // unsigned saturating subtract: operands are >= 0, result clamps at 0
+    static __device__ __forceinline__ V subz(V a, V b) { return (V)__builtin_elementwise_sub_sat((v2u)a, (v2u)b); }
+};
+
+// ---- cell arithmetic, int32 (promotion tier) ----------------------------------------------
+struct OpsI32 {
+    typedef int V;
+    static __device__ __forceinline__ V zero() { return 0; }
+    static __device__ __forceinline__ V splat(int x) { return x; }
+    static __device__ __forceinline__ V from_bits(uint32_t x) { return (int)x; }
+    static __device__ __forceinline__ uint32_t bits(V x) { return (uint32_t)x; }
+    static __device__ __forceinline__ V adds(V a, V b) { return a + b; }
+    static __device__ __forceinline__ V vmax(V a, V b) { return a > b ? a : b; }
+    static __device__ __forceinline__ V subz(V a, V b) { int d = a - b; return d > 0 ? d : 0; }
+};
+
+template <class Ops>
+__device__ __forceinline__ void cell(typename Ops::V &hd, typename Ops::V &Hr, typename Ops::V &Er,
+                                     typename Ops::V &F, typename Ops::V &best, typename Ops::V S,
+                                     typename Ops::V goe, typename Ops::V ge)
+{
+    typedef typename Ops::V V;
+    V t = Ops::adds(hd, S);           // Hdiag + S            (CPUsearch.c:622)
+    hd = Hr;                          // next row's diagonal = this row's previous column
+    V h = Ops::vmax(Ops::vmax(t, Er), F);   // max with E and F (>= 0 already: CPUsearch.c:624-626)
+    Hr = h;
+    best = Ops::vmax(best, h);        // CPUsearch.c:636
+    // opaque to the optimiser: otherwise it re-associates the running max into one big reduction
+    // at the end of the chunk and keeps all 4*T h values alive (60+ VGPR spills)
+    asm("" : "+v"(best));
+    V u = Ops::subz(h, goe);          // H - (open+extend)    (CPUsearch.c:630)
+    Er = Ops::vmax(Ops::subz(Er, ge), u);   // CPUsearch.c:628,631
+    F = Ops::vmax(Ops::subz(F, ge), u);     // CPUsearch.c:629,632
+}
+
+__host__ __device__ constexpr size_t round16(size_t x) { return (x + 15) & ~(size_t)15; }
+// +16: the 25 code rows start 16 bytes (mod 256) apart, so codes d and d' share LDS banks for
+// ds_read_b128 only when d == d' (mod 16)
+__host__ __device__ constexpr int prof_row_bytes(int rows) { return rows * 2 + 16; }
+
+size_t pipe_lds_bytes(int T, int W)
+{
+    return round16((size_t)kCodes * prof_row_bytes(T * W)) + (size_t)W * 2 * kChunkCols * 64 * sizeof(uint2);
+}
+
+template <int T, bool PK>
+__global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
+{
+    typedef typename std::conditional<PK, OpsPK, OpsI32>::type Ops;
+    typedef typename Ops::V V;
+    constexpr int C = kChunkCols;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int W = blockDim.x >> 6;
+    const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index = query strip
+    const int lane = threadIdx.x & 63;
+    const int RW = W * T;
+    const int PS = prof_row_bytes(RW);
+    unsigned char *prof_lds = smem;
+    uint2 *ring = (uint2 *)(smem + round16((size_t)kCodes * PS));
+
+    // stage this pass's window of the query profile: rows [r0, r0 + W*T) of all 25 codes
+    {
+        const int dw_per_code = RW >> 1;
+        for (int idx = threadIdx.x; idx < kCodes * dw_per_code; idx += blockDim.x) {
+            const int d = idx / dw_per_code, x = idx - d * dw_per_code;
+            const uint32_t *src = (const uint32_t *)(p.prof + (size_t)d * p.prof_stride + p.r0);
+            *(uint32_t *)(prof_lds + d * PS + x * 4) = src[x];
+        }
+    }
+    __syncthreads();
+
+    const V goe = Ops::splat(p.goe), ge = Ops::splat(p.ge);
+    const uint32_t it_end = p.wg_first[blockIdx.x + 1];
+    uint32_t it = p.wg_first[blockIdx.x];
+    const int total = (int)p.wg_chunks[blockIdx.x];
+    const int nsteps = total + W - 1;
+    const unsigned char *my_prof = prof_lds + k * T * 2;
+
+    V H[T], E[T];
+    V best = Ops::zero(), diag_top = Ops::zero();
+#pragma unroll
+    for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+
+    uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, out_slot = 0;
+    uint64_t bnd_off = 0;
+    const uint8_t *dbp = nullptr;
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int c = s - k;                      // global chunk index of this wave in this step
+        if (c >= 0 && c < total && it < it_end) { // wave-uniform
+            if (cc == 0) {                        // first chunk of a new item: reset the DP state
+                const Item iv = p.items[it];
+                const GroupDesc g = p.groups[iv.group];
+                nch = g.ncols / C; dbp = g.db; seq0 = g.seq0;
+                half = iv.half; out_slot = iv.out_slot; bnd_off = iv.bnd_off;
+                best = Ops::zero(); diag_top = Ops::zero();
+#pragma unroll
+                for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+            }
+            // database residues of this chunk: 4 columns of the lane's sequence(s)
+            uint32_t wa, wb = 0;
+            if (PK) {
+                const uint2 w = *(const uint2 *)(dbp + ((size_t)cc * 64 + lane) * 8);
+                wa = w.x; wb = w.y;
+            } else {
+                wa = *(const uint32_t *)(dbp + ((size_t)cc * 64 + lane) * 8 + half * 4);
+            }
+            // top boundary of the strip for these columns: H of the row above, F entering row 0
+            uint2 bin[C], bout[C];
+            if (k == 0) {
+                if (p.first_pass) {
+#pragma unroll
+                    for (int jj = 0; jj < C; ++jj) bin[jj] = make_uint2(0u, 0u);
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < C; ++jj) bin[jj] = p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane];
+                }
+            } else {
+                const uint2 *src = ring + (size_t)(((k - 1) * 2 + (c & 1)) * C) * 64 + lane;
+#pragma unroll
+                for (int jj = 0; jj < C; ++jj) bin[jj] = src[jj * 64];
+            }
+#pragma unroll
+            for (int jj = 0; jj < C; ++jj) {
+                const uint32_t da = (wa >> (8 * jj)) & 0xffu;
+                const unsigned char *pa = my_prof + da * PS;
+                const unsigned char *pb = pa;
+                if (PK) pb = my_prof + ((wb >> (8 * jj)) & 0xffu) * PS;
+                V hd = diag_top;
+                diag_top = Ops::from_bits(bin[jj].x);
+                V F = Ops::from_bits(bin[jj].y);
+#pragma unroll
+                for (int r8 = 0; r8 < T / 8; ++r8) {
+                    // one ds_read_b128 = the scores of 8 consecutive query rows for this lane's residue
+                    const uint4 a = *(const uint4 *)(pa + r8 * 16);
+                    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+                    if (PK) {
+                        const uint4 b = *(const uint4 *)(pb + r8 * 16);
+                        const uint32_t bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            // (A_r, B_r) pairs: low / high int16 of the two lookups
+                            const int r = r8 * 8 + q * 2;
+                            cell<Ops>(hd, H[r], E[r], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)), goe, ge);
+                            cell<Ops>(hd, H[r + 1], E[r + 1], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r = r8 * 8 + q * 2;
+                            cell<Ops>(hd, H[r], E[r], F, best, Ops::from_bits((uint32_t)(int)(short)(aw[q] & 0xffffu)), goe, ge);
+                            cell<Ops>(hd, H[r + 1], E[r + 1], F, best, Ops::from_bits((uint32_t)((int)aw[q] >> 16)), goe, ge);
+                        }
+                    }
+                }
+                bout[jj] = make_uint2(Ops::bits(H[T - 1]), Ops::bits(F));
+                // keep one column's lookups in flight at a time: without this fence the scheduler hoists
+                // all four columns' LDS reads and the kernel needs ~230 VGPRs (spills at 3 waves/SIMD)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // bottom boundary: to the next wave through LDS, or (last wave, more passes) to HBM
+            if (k < W - 1) {
+                uint2 *dst = ring + (size_t)((k * 2 + (c & 1)) * C) * 64 + lane;
+#pragma unroll
+                for (int jj = 0; jj < C; ++jj) dst[jj * 64] = bout[jj];
+            } else if (!p.last_pass) {
+#pragma unroll
+                for (int jj = 0; jj < C; ++jj) p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = bout[jj];
+            }
+            if (++cc == nch) {   // item finished: every strip contributes its best (CPUsearch.c:670-676)
+                if (PK) {
+                    const v2s b2 = __builtin_bit_cast(v2s, Ops::bits(best));
+                    atomicMax(p.out + seq0 + lane, (int)b2.x);
+                    atomicMax(p.out + seq0 + 64 + lane, (int)b2.y);
+                } else {
+                    atomicMax(p.out + (size_t)out_slot * 64 + lane, (int)Ops::bits(best));
+                }
+                cc = 0;
+                ++it;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int T, bool PK>
+static hipError_t launch_one(int W, int n_wg, const PipeParams &p, hipStream_t s)
+{
+    const size_t lds = pipe_lds_bytes(T, W);
+    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sw_pipe_kernel<T, PK>), dim3(n_wg), dim3(W * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_pipe(Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t s)
+{
+    if (W < 1 || W > kMaxWaves || n_wg < 1) return hipErrorInvalidValue;
+    const bool pk = mode == Mode::PK16;
+    if (T == 32) return pk ? launch_one<32, true>(W, n_wg, p, s) : launch_one<32, false>(W, n_wg, p, s);
+    if (T == 16) return pk ? launch_one<16, true>(W, n_wg, p, s) : launch_one<16, false>(W, n_wg, p, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t pipe_kernel_attributes(Mode mode, int T, int *num_regs)
+{
+    hipFuncAttributes a;
+    const void *f = nullptr;
+    const bool pk = mode == Mode::PK16;
+    if (T == 32) f = pk ? (const void *)sw_pipe_kernel<32, true> : (const void *)sw_pipe_kernel<32, false>;
+    else if (T == 16) f = pk ? (const void *)sw_pipe_kernel<16, true> : (const void *)sw_pipe_kernel<16, false>;
+    else return hipErrorInvalidValue;
+    hipError_t e = hipFuncGetAttributes(&a, f);
+    if (e == hipSuccess) *num_regs = a.numRegs;
+    return e;
+}
+
+// ---- re-tile: reference chunk layout -> device groups --------------------------------------
+// reference byte of VL-group v, position j, lane kk: b[disp[v] + j*vl + kk]   (sequences.c:508-513)
+// device dword of group g, chunk c, lane l: tiled[goff[g] + (c*64 + l)*8 + {0: seq l, 4: seq 64+l}]
+__global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__restrict__ n,
+                              const uint32_t *__restrict__ disp, uint32_t vl_groups, uint32_t vl,
+                              const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols,
+                              uint8_t *__restrict__ tiled)
+{
+    const uint32_t g = blockIdx.x;
+    const uint32_t nch = gcols[g] / kChunkCols;
+    const uint32_t per = kGroupSeqs / vl;            // VL-groups per device group
+    for (uint32_t idx = threadIdx.x; idx < nch * 64; idx += blockDim.x) {
+        const uint32_t c = idx >> 6, l = idx & 63;
+        uint32_t w[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const uint32_t sl = l + 64 * hh;          // sequence within the device group
+            const uint32_t v = g * per + sl / vl, kk = sl % vl;
+            uint32_t word = 0;
+#pragma unroll
+            for (int jj = 0; jj < kChunkCols; ++jj) {
+                const uint32_t col = c * kChunkCols + jj;
+                uint32_t code = 24;                   // PREPROCESSED_DUMMY_ELEMENT, sequences.h:18
+                if (v < vl_groups && col < n[v]) {
+                    code = b[(size_t)disp[v] + (size_t)col * vl + kk];
+                    if (code > 24) code = 24;         // out-of-alphabet bytes score like padding
+                }
+                word |= code << (8 * jj);
+            }
+            w[hh] = word;
+        }
+        *(uint2 *)(tiled + goff[g] + (size_t)idx * 8) = make_uint2(w[0], w[1]);
+    }
+}
+
+hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t vl_groups, uint32_t vl,
+                         const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled, hipStream_t s)
+{
+    if (dev_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(retile_kernel, dim3(dev_groups), dim3(256), 0, s, b, n, disp, vl_groups, vl, goff, gcols, tiled);
+    return hipGetLastError();
+}
+
+// ---- saturation bookkeeping ----------------------------------------------------------------
+__global__ void flag_saturated_kernel(const int32_t *__restrict__ scores, uint64_t n, uint8_t *__restrict__ flags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool sat = i < n && scores[i] >= 32767;
+    const unsigned long long m = __ballot(sat);
+    if ((threadIdx.x & 63) == 0 && i < n) flags[i >> 6] = m ? 1 : 0;
+}
+
+hipError_t launch_flag_saturated(const int32_t *scores, uint64_t n, uint8_t *flags, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(flag_saturated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, n, flags);
+    return hipGetLastError();
+}
+
+__global__ void reset_halves_kernel(int32_t *scores, const uint32_t *half_slots, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i < count) scores[(size_t)half_slots[i] * 64 + (threadIdx.x & 63)] = 0;
+}
+
+hipError_t launch_reset_halves(int32_t *scores, const uint32_t *half_slots, uint32_t count, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(reset_halves_kernel, dim3((count + 3) / 4), dim3(256), 0, s, scores, half_slots, count);
+    return hipGetLastError();
+}
+
+}  // namespace swimm

@@ -1,0 +1,653 @@
+// swimm_hip.cpp -- C-ABI shim of libswimm_hip.so (see include/swimm_hip.h).
+//
+// Host-side orchestration of the gfx950 kernels in sw_kernels.hip: device-resident database,
+// per-query launch plan (rows per wave T, waves per workgroup W, passes), static LPT partition
+// of the device groups over persistent workgroups, int16 -> int32 promotion, score scatter.
+// Structural template: mic_search_knc_ap_multiple_chunks (MICsearch.c:4-354) -- X1 = set_queries,
+// X2-in = add_chunk (kept resident), compute = search, X3 = scatter into the caller's scores.
+#include "../../include/swimm_hip.h"
+#include "sw_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace swimm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) return fail("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T>
+struct DevBuf {   // grow-only device scratch
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Plan {      // static partition of a work list over n_wg persistent workgroups
+    int n_wg = 0;
+    DevBuf<Item> items;
+    DevBuf<uint32_t> wg_first, wg_chunks;
+    uint64_t bnd_cols = 0;   // columns the pass-boundary buffer must hold
+    uint64_t max_wg_chunks = 0, total_chunks = 0;
+    void release() { items.release(); wg_first.release(); wg_chunks.release(); }
+};
+
+struct ChunkRec {
+    uint8_t *d_tiled = nullptr;
+    uint64_t first_seq = 0;     // global sorted index of the chunk's first sequence
+    uint64_t n_seq = 0;         // group_count * vl
+    uint32_t group0 = 0, n_groups = 0;
+};
+
+struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; };
+
+}  // namespace
+
+struct swimm_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cu = 0;
+    // options
+    int opt_T = 32, opt_maxW = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;
+    // queries (host copies; profiles are built per search because T/W may change)
+    std::vector<int8_t> qcodes;
+    std::vector<uint16_t> qm;
+    std::vector<uint32_t> qdisp;
+    int8_t submat[SWIMM_HIP_SUBMAT_BYTES];
+    int open_gap = 10, extend_gap = 2, max_pos = 0;
+    bool have_queries = false;
+    // database
+    std::vector<ChunkRec> chunks;
+    std::vector<GroupDesc> groups;
+    std::vector<uint64_t> group_col_off;
+    uint64_t total_cols = 0;
+    DevBuf<GroupDesc> d_groups;
+    bool groups_dirty = true;
+    std::map<int, Plan> plans;          // key: n_wg (packed mode), n_wg | 1<<30 (whole-db int32 mode)
+    // scratch
+    DevBuf<int32_t> d_scores;
+    DevBuf<int16_t> d_prof;
+    DevBuf<uint2> d_bnd;
+    DevBuf<uint8_t> d_flags;
+    DevBuf<uint32_t> d_slots;
+    // stats of the last search
+    double kernel_ms = 0;
+    uint64_t cells = 0, promoted = 0;
+    uint32_t launches = 0;
+};
+
+namespace {
+
+int regs_to_waves_per_simd(int regs)
+{
+    const int alloc = (regs + 7) / 8 * 8;   // MI355X_MICROARCH: 8-register granule, 512 per SIMD lane
+    return std::max(1, std::min(8, 512 / std::max(alloc, 8)));
+}
+
+// T rows per wave, W waves per workgroup, number of passes for a query of m rows
+QueryPlan choose_plan(const swimm_hip_ctx *c, int m)
+{
+    QueryPlan q{};
+    q.T = (c->opt_T == 16) ? 16 : 32;
+    int maxW = (q.T == 32) ? 12 : 16;       // __launch_bounds__ of the two instantiations
+    if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
+    const int strips = std::max(1, (m + q.T - 1) / q.T);
+    q.passes = (strips + maxW - 1) / maxW;
+    q.W = (strips + q.passes - 1) / q.passes;
+    q.mpad = (uint32_t)(q.passes * q.W * q.T);
+    return q;
+}
+
+int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
+{
+    int regs = 0;
+    HIP_TRY(pipe_kernel_attributes(mode, T, &regs));
+    const int waves_cu = 4 * regs_to_waves_per_simd(regs);
+    const size_t lds = pipe_lds_bytes(T, W);
+    int n = std::min(waves_cu / W, (int)(163840 / lds));
+    if (c->opt_wgs_per_cu > 0) n = c->opt_wgs_per_cu;
+    *out = std::max(1, n);
+    return 0;
+}
+
+struct WorkUnit { uint32_t group, half, out_slot; uint32_t ncols; uint64_t bnd_off; };
+
+// LPT: longest unit first onto the least-loaded workgroup; cost = columns (exact, every column of a
+// unit costs the same T*W*128 cells)
+int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, Plan &pl)
+{
+    n_wg = std::max(1, std::min<int>(n_wg, (int)units.size()));
+    std::vector<uint32_t> order(units.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return units[a].ncols > units[b].ncols; });
+    typedef std::pair<uint64_t, int> Load;
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int w = 0; w < n_wg; ++w) heap.push(Load(0, w));
+    std::vector<std::vector<uint32_t>> bins(n_wg);
+    std::vector<uint64_t> load(n_wg, 0);
+    for (uint32_t idx : order) {
+        Load l = heap.top(); heap.pop();
+        bins[l.second].push_back(idx);
+        load[l.second] = l.first + units[idx].ncols;
+        heap.push(Load(load[l.second], l.second));
+    }
+    std::vector<Item> items; items.reserve(units.size());
+    std::vector<uint32_t> first(n_wg + 1, 0), chunks(n_wg, 0);
+    pl.max_wg_chunks = 0; pl.total_chunks = 0;
+    for (int w = 0; w < n_wg; ++w) {
+        first[w] = (uint32_t)items.size();
+        for (uint32_t idx : bins[w]) {
+            const WorkUnit &u = units[idx];
+            Item it{}; it.group = u.group; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = u.bnd_off;
+            items.push_back(it);
+        }
+        chunks[w] = (uint32_t)(load[w] / kChunkCols);
+        pl.max_wg_chunks = std::max<uint64_t>(pl.max_wg_chunks, chunks[w]);
+        pl.total_chunks += chunks[w];
+    }
+    first[n_wg] = (uint32_t)items.size();
+    pl.n_wg = n_wg;
+    HIP_TRY(pl.items.reserve(items.size()));
+    HIP_TRY(pl.wg_first.reserve(first.size()));
+    HIP_TRY(pl.wg_chunks.reserve(chunks.size()));
+    HIP_TRY(hipMemcpyAsync(pl.items.p, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(pl.wg_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(pl.wg_chunks.p, chunks.data(), chunks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the host vectors die here
+    return 0;
+}
+
+int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, Plan **out)
+{
+    const int key = n_wg | (mode == Mode::I32 ? (1 << 30) : 0);
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) { *out = &it->second; return 0; }
+    std::vector<WorkUnit> units;
+    uint64_t bnd_cols = 0;
+    if (mode == Mode::PK16) {
+        units.reserve(c->groups.size());
+        for (uint32_t g = 0; g < c->groups.size(); ++g)
+            units.push_back(WorkUnit{g, 0, 0, c->groups[g].ncols, c->group_col_off[g]});
+        bnd_cols = c->total_cols;
+    } else {
+        units.reserve(c->groups.size() * 2);
+        for (uint32_t g = 0; g < c->groups.size(); ++g)
+            for (uint32_t h = 0; h < 2; ++h)
+                units.push_back(WorkUnit{g, h, c->groups[g].seq0 / 64 + h, c->groups[g].ncols,
+                                         2 * c->group_col_off[g] + (uint64_t)h * c->groups[g].ncols});
+        bnd_cols = 2 * c->total_cols;
+    }
+    Plan &pl = c->plans[key];
+    if (build_plan(c, units, n_wg, pl)) return 1;
+    pl.bnd_cols = bnd_cols;
+    *out = &pl;
+    return 0;
+}
+
+int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row)
+{
+    if (qp.passes > 1) HIP_TRY(c->d_bnd.reserve(pl.bnd_cols * 64));
+    for (int pass = 0; pass < qp.passes; ++pass) {
+        PipeParams p{};
+        p.groups = c->d_groups.p;
+        p.items = pl.items.p;
+        p.wg_first = pl.wg_first.p;
+        p.wg_chunks = pl.wg_chunks.p;
+        p.prof = c->d_prof.p + qp.prof_off;
+        p.prof_stride = qp.mpad;
+        p.r0 = (uint32_t)(pass * qp.W * qp.T);
+        p.bnd = c->d_bnd.p;
+        p.first_pass = pass == 0;
+        p.last_pass = pass == qp.passes - 1;
+        p.out = out_row;
+        p.goe = c->open_gap + c->extend_gap;
+        p.ge = c->extend_gap;
+        HIP_TRY(launch_pipe(mode, qp.T, qp.W, pl.n_wg, p, c->stream));
+        c->launches++;
+        c->cells += pl.total_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * (mode == Mode::PK16 ? 128 : 64);
+    }
+    return 0;
+}
+
+int upload_groups(swimm_hip_ctx *c)
+{
+    if (!c->groups_dirty) return 0;
+    HIP_TRY(c->d_groups.reserve(c->groups.size()));
+    HIP_TRY(hipMemcpyAsync(c->d_groups.p, c->groups.data(), c->groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &kv : c->plans) kv.second.release();
+    c->plans.clear();
+    c->groups_dirty = false;
+    return 0;
+}
+
+// device part of a search: leaves exact scores in d_scores[q * S + local_slot]
+int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
+{
+    if (!c->have_queries) return fail("swimm_hip_search: no queries set");
+    if (c->groups.empty()) return fail("swimm_hip_search: no database chunk resident");
+    HIP_TRY(hipSetDevice(c->device));
+    if (upload_groups(c)) return 1;
+    const uint32_t qn = (uint32_t)c->qm.size();
+    const uint64_t S = (uint64_t)c->groups.size() * kGroupSeqs;
+    *slots_out = S;
+    c->kernel_ms = 0; c->cells = 0; c->promoted = 0; c->launches = 0;
+
+    // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
+    // transposed so that consecutive query rows are contiguous for one residue code)
+    std::vector<QueryPlan> qps(qn);
+    size_t prof_elems = 0;
+    for (uint32_t q = 0; q < qn; ++q) {
+        qps[q] = choose_plan(c, c->qm[q]);
+        qps[q].prof_off = prof_elems;
+        prof_elems += (size_t)kCodes * qps[q].mpad;
+    }
+    std::vector<int16_t> prof(prof_elems, 0);
+    for (uint32_t q = 0; q < qn; ++q) {
+        const int8_t *qa = c->qcodes.data() + c->qdisp[q];
+        for (int d = 0; d < kCodes; ++d) {
+            int16_t *row = prof.data() + qps[q].prof_off + (size_t)d * qps[q].mpad;
+            for (uint32_t r = 0; r < c->qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + d];
+        }
+    }
+    HIP_TRY(c->d_prof.reserve(prof_elems));
+    HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c->d_scores.reserve((size_t)qn * S));
+    HIP_TRY(hipMemsetAsync(c->d_scores.p, 0, (size_t)qn * S * sizeof(int32_t), c->stream));
+
+    const Mode main_mode = c->opt_force_i32 ? Mode::I32 : Mode::PK16;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (uint32_t q = 0; q < qn; ++q) {
+        int per_cu = 1;
+        if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
+        Plan *pl = nullptr;
+        if (get_db_plan(c, main_mode, c->num_cu * per_cu, &pl)) return 1;
+        if (run_passes(c, main_mode, qps[q], *pl, c->d_scores.p + (size_t)q * S)) return 1;
+    }
+    // promotion: lanes whose int16 best saturated are recomputed in int32 (CPUsearch.c:820-957)
+    if (main_mode == Mode::PK16) {
+        std::vector<uint8_t> flags(S / 64);
+        for (uint32_t q = 0; q < qn; ++q) {
+            if ((long)c->qm[q] * c->max_pos < 32767) continue;   // cannot saturate
+            int32_t *row = c->d_scores.p + (size_t)q * S;
+            HIP_TRY(c->d_flags.reserve(S / 64));
+            HIP_TRY(launch_flag_saturated(row, S, c->d_flags.p, c->stream));
+            HIP_TRY(hipMemcpyAsync(flags.data(), c->d_flags.p, S / 64, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            std::vector<WorkUnit> units;
+            std::vector<uint32_t> slots;
+            uint64_t cols = 0;
+            for (uint32_t g = 0; g < c->groups.size(); ++g)
+                for (uint32_t h = 0; h < 2; ++h) {
+                    const uint32_t slot = c->groups[g].seq0 / 64 + h;
+                    if (!flags[slot]) continue;
+                    units.push_back(WorkUnit{g, h, slot, c->groups[g].ncols, cols});
+                    slots.push_back(slot);
+                    cols += c->groups[g].ncols;
+                }
+            if (units.empty()) continue;
+            c->promoted += units.size() * 64;
+            HIP_TRY(c->d_slots.reserve(slots.size()));
+            HIP_TRY(hipMemcpyAsync(c->d_slots.p, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(launch_reset_halves(row, c->d_slots.p, (uint32_t)slots.size(), c->stream));
+            int per_cu = 1;
+            if (wgs_per_cu(c, Mode::I32, qps[q].T, qps[q].W, &per_cu)) return 1;
+            Plan pl;
+            if (build_plan(c, units, c->num_cu * per_cu, pl)) return 1;
+            pl.bnd_cols = cols;
+            const int rc = run_passes(c, Mode::I32, qps[q], pl, row);
+            if (rc == 0) HIP_TRY(hipStreamSynchronize(c->stream));
+            pl.release();
+            if (rc) return 1;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->kernel_ms = ms;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int swimm_hip_abi_version(void) { return SWIMM_HIP_ABI_VERSION; }
+
+const char *swimm_hip_last_error(void) { return g_err.c_str(); }
+
+int swimm_hip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { fail("hipGetDeviceCount: %s", hipGetErrorString(e)); return 0; }
+    if (n == 0) fail("no HIP device visible");
+    return n;
+}
+
+int swimm_hip_create(int device, swimm_hip_ctx **out)
+{
+    if (!out) return fail("swimm_hip_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail("swimm_hip_create: device %d not in [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("swimm_hip_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+    swimm_hip_ctx *c = new swimm_hip_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail("swimm_hip_create: stream/event creation failed");
+    }
+    *out = c;
+    return 0;
+}
+
+void swimm_hip_destroy(swimm_hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    swimm_hip_clear_db(c);
+    c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
+    c->d_flags.release(); c->d_slots.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int swimm_hip_set_queries(swimm_hip_ctx *c, const char *a, const uint16_t *m, const uint32_t *a_disp,
+                          uint32_t query_count, const char *submat, int open_gap, int extend_gap)
+{
+    if (!c || !a || !m || !a_disp || !submat) return fail("swimm_hip_set_queries: NULL argument");
+    if (query_count == 0) return fail("swimm_hip_set_queries: no queries");
+    if (open_gap < 0 || extend_gap < 0 || open_gap + extend_gap > 127)
+        return fail("swimm_hip_set_queries: need 0 <= open, extend and open+extend <= 127 (got %d, %d)", open_gap, extend_gap);
+    size_t total = 0;
+    for (uint32_t q = 0; q < query_count; ++q) {
+        if (m[q] == 0) return fail("swimm_hip_set_queries: query %u is empty", q);
+        total = std::max<size_t>(total, (size_t)a_disp[q] + m[q]);
+    }
+    for (size_t i = 0; i < total; ++i)
+        if ((unsigned char)a[i] > 23) return fail("swimm_hip_set_queries: residue code %d at %zu is outside 0..23", (int)a[i], i);
+    c->qcodes.assign((const int8_t *)a, (const int8_t *)a + total);
+    c->qm.assign(m, m + query_count);
+    c->qdisp.assign(a_disp, a_disp + query_count);
+    memcpy(c->submat, submat, SWIMM_HIP_SUBMAT_BYTES);
+    c->open_gap = open_gap; c->extend_gap = extend_gap;
+    c->max_pos = 0;
+    for (int i = 0; i < SWIMM_HIP_SUBMAT_BYTES; ++i) c->max_pos = std::max<int>(c->max_pos, c->submat[i]);
+    c->have_queries = true;
+    return 0;
+}
+
+int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint16_t *n, const uint32_t *b_disp,
+                        uint32_t group_count, uint32_t vl, uint64_t first_group)
+{
+    if (!c || !b || !n || !b_disp) return fail("swimm_hip_add_chunk: NULL argument");
+    if (group_count == 0) return fail("swimm_hip_add_chunk: empty chunk");
+    if (vl == 0 || vl > (uint32_t)kGroupSeqs || kGroupSeqs % vl != 0)
+        return fail("swimm_hip_add_chunk: lane width %u must divide %d", vl, kGroupSeqs);
+    if (vD > 0xFFFFFFFFull) return fail("swimm_hip_add_chunk: chunk larger than 4 GiB");
+    for (uint32_t g = 0; g < group_count; ++g)
+        if ((uint64_t)b_disp[g] + (uint64_t)n[g] * vl > vD)
+            return fail("swimm_hip_add_chunk: group %u (disp %u, n %u) runs past vD=%llu", g, b_disp[g], n[g], (unsigned long long)vD);
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t per = kGroupSeqs / vl;
+    const uint32_t dev_groups = (group_count + per - 1) / per;
+    std::vector<uint64_t> goff(dev_groups);
+    std::vector<uint32_t> gcols(dev_groups);
+    uint64_t bytes = 0;
+    for (uint32_t g = 0; g < dev_groups; ++g) {
+        uint32_t mx = 0;
+        for (uint32_t v = g * per; v < std::min(group_count, (g + 1) * per); ++v) mx = std::max<uint32_t>(mx, n[v]);
+        mx = std::max<uint32_t>(mx, 1);
+        gcols[g] = (mx + kChunkCols - 1) / kChunkCols * kChunkCols;
+        goff[g] = bytes;
+        bytes += (uint64_t)gcols[g] * kGroupSeqs;
+    }
+    uint8_t *d_b = nullptr, *d_tiled = nullptr;
+    uint16_t *d_n = nullptr;
+    uint32_t *d_disp = nullptr, *d_gcols = nullptr;
+    uint64_t *d_goff = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_b); (void)hipFree(d_n); (void)hipFree(d_disp); (void)hipFree(d_gcols); (void)hipFree(d_goff); };
+#define TRY_OR_CLEAN(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); (void)hipFree(d_tiled); return fail("%s: %s", #expr, hipGetErrorString(e__)); } } while (0)
+    TRY_OR_CLEAN(hipMalloc((void **)&d_b, vD));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_n, group_count * sizeof(uint16_t)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_disp, group_count * sizeof(uint32_t)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_gcols, dev_groups * sizeof(uint32_t)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_goff, dev_groups * sizeof(uint64_t)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_tiled, bytes));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_b, b, vD, hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_n, n, group_count * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_disp, b_disp, group_count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_gcols, gcols.data(), dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_goff, goff.data(), dev_groups * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(launch_retile(d_b, d_n, d_disp, group_count, vl, d_goff, d_gcols, dev_groups, d_tiled, c->stream));
+    TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
+#undef TRY_OR_CLEAN
+    cleanup();
+    ChunkRec rec;
+    rec.d_tiled = d_tiled;
+    rec.first_seq = first_group * vl;
+    rec.n_seq = (uint64_t)group_count * vl;
+    rec.group0 = (uint32_t)c->groups.size();
+    rec.n_groups = dev_groups;
+    for (uint32_t g = 0; g < dev_groups; ++g) {
+        GroupDesc gd;
+        gd.db = d_tiled + goff[g];
+        gd.ncols = gcols[g];
+        gd.seq0 = (uint32_t)((rec.group0 + g) * kGroupSeqs);
+        c->groups.push_back(gd);
+        c->group_col_off.push_back(c->total_cols);
+        c->total_cols += gcols[g];
+    }
+    c->chunks.push_back(rec);
+    c->groups_dirty = true;
+    return 0;
+}
+
+int swimm_hip_clear_db(swimm_hip_ctx *c)
+{
+    if (!c) return fail("swimm_hip_clear_db: NULL ctx");
+    (void)hipSetDevice(c->device);
+    for (auto &ch : c->chunks) (void)hipFree(ch.d_tiled);
+    c->chunks.clear(); c->groups.clear(); c->group_col_off.clear();
+    c->total_cols = 0;
+    for (auto &kv : c->plans) kv.second.release();
+    c->plans.clear();
+    c->groups_dirty = true;
+    return 0;
+}
+
+int swimm_hip_search(swimm_hip_ctx *c, int32_t *scores, uint64_t score_stride, double *work_time)
+{
+    if (!c || !scores) return fail("swimm_hip_search: NULL argument");
+    const double t0 = now_s();
+    uint64_t S = 0;
+    if (search_device(c, &S)) return 1;
+    // score scatter (X3, MICsearch.c:333-334): each chunk's slice goes to its global offset
+    const uint32_t qn = (uint32_t)c->qm.size();
+    for (const ChunkRec &ch : c->chunks) {
+        if (ch.first_seq + ch.n_seq > score_stride)
+            return fail("swimm_hip_search: chunk at %llu+%llu exceeds score_stride %llu", (unsigned long long)ch.first_seq,
+                        (unsigned long long)ch.n_seq, (unsigned long long)score_stride);
+        HIP_TRY(hipMemcpy2DAsync(scores + ch.first_seq, score_stride * sizeof(int32_t),
+                                 c->d_scores.p + (size_t)ch.group0 * kGroupSeqs, S * sizeof(int32_t),
+                                 ch.n_seq * sizeof(int32_t), qn, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (work_time) *work_time = now_s() - t0;
+    return 0;
+}
+
+int swimm_hip_search_topr(swimm_hip_ctx *c, uint32_t r, uint64_t n_valid, int32_t *top_scores, int64_t *top_index,
+                          double *work_time)
+{
+    if (!c || !top_scores || !top_index) return fail("swimm_hip_search_topr: NULL argument");
+    if (r == 0) return fail("swimm_hip_search_topr: r must be > 0");
+    const double t0 = now_s();
+    uint64_t S = 0;
+    if (search_device(c, &S)) return 1;
+    const uint32_t qn = (uint32_t)c->qm.size();
+    std::vector<int32_t> host((size_t)qn * S);
+    HIP_TRY(hipMemcpyAsync(host.data(), c->d_scores.p, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // key = (score, global index): larger key first == score desc, then larger index first (utils.c:12,52)
+    typedef std::pair<int32_t, int64_t> Hit;
+    std::vector<Hit> hits;
+    for (uint32_t q = 0; q < qn; ++q) {
+        hits.clear();
+        for (const ChunkRec &ch : c->chunks) {
+            const int32_t *row = host.data() + (size_t)q * S + (size_t)ch.group0 * kGroupSeqs;
+            for (uint64_t i = 0; i < ch.n_seq; ++i) {
+                const uint64_t gi = ch.first_seq + i;
+                if (gi < n_valid) hits.push_back(Hit(row[i], (int64_t)gi));
+            }
+        }
+        const size_t k = std::min<size_t>(r, hits.size());
+        std::partial_sort(hits.begin(), hits.begin() + k, hits.end(), std::greater<Hit>());
+        for (uint32_t i = 0; i < r; ++i) {
+            top_scores[(size_t)q * r + i] = i < k ? hits[i].first : -1;
+            top_index[(size_t)q * r + i] = i < k ? hits[i].second : -1;
+        }
+    }
+    if (work_time) *work_time = now_s() - t0;
+    return 0;
+}
+
+int swimm_hip_last_stats(swimm_hip_ctx *c, double *kernel_ms, uint64_t *cells, uint64_t *promoted, uint32_t *launches)
+{
+    if (!c) return fail("swimm_hip_last_stats: NULL ctx");
+    if (kernel_ms) *kernel_ms = c->kernel_ms;
+    if (cells) *cells = c->cells;
+    if (promoted) *promoted = c->promoted;
+    if (launches) *launches = c->launches;
+    return 0;
+}
+
+int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return fail("swimm_hip_set_option: NULL argument");
+    if (!strcmp(key, "rows_per_wave")) {
+        if (value != 16 && value != 32) return fail("rows_per_wave must be 16 or 32");
+        c->opt_T = value;
+    } else if (!strcmp(key, "max_waves")) {
+        if (value < 0 || value > kMaxWaves) return fail("max_waves must be 0..%d", kMaxWaves);
+        c->opt_maxW = value;
+    } else if (!strcmp(key, "force_i32")) {
+        c->opt_force_i32 = value != 0;
+    } else if (!strcmp(key, "wgs_per_cu")) {
+        if (value < 0 || value > 16) return fail("wgs_per_cu must be 0..16");
+        c->opt_wgs_per_cu = value;
+        for (auto &kv : c->plans) kv.second.release();
+        c->plans.clear();
+    } else {
+        return fail("swimm_hip_set_option: unknown key '%s'", key);
+    }
+    return 0;
+}
+
+int swimm_hip_search_chunks(const char *query_sequences, const uint16_t *query_sequences_lengths,
+                            uint32_t query_sequences_count, const uint32_t *query_disp,
+                            uint64_t vect_sequences_db_count, char **chunk_b, uint32_t chunk_count,
+                            const uint32_t *chunk_vect_sequences_db_count, uint16_t **chunk_n,
+                            uint32_t **chunk_b_disp, const uint64_t *chunk_vD, const char *submat,
+                            int open_gap, int extend_gap, int num_gpus, uint32_t vl, int32_t *scores,
+                            double *workTime)
+{
+    if (!chunk_b || !chunk_vect_sequences_db_count || !chunk_n || !chunk_b_disp || !chunk_vD || !scores)
+        return fail("swimm_hip_search_chunks: NULL argument");
+    if (chunk_count == 0) return fail("swimm_hip_search_chunks: no chunks");
+    const int avail = swimm_hip_device_count();
+    if (avail <= 0) return 1;
+    if (num_gpus <= 0 || num_gpus > avail) return fail("swimm_hip_search_chunks: %d GPUs requested, %d visible", num_gpus, avail);
+    const double t0 = now_s();
+    // chunk_accum_vect_sequences_db_count, MICsearch.c:46-49
+    std::vector<uint64_t> accum(chunk_count, 0);
+    for (uint32_t i = 1; i < chunk_count; ++i) accum[i] = accum[i - 1] + chunk_vect_sequences_db_count[i - 1];
+    // static shard (north_star): chunks dealt longest-first onto the least-loaded GPU, cost = padded bytes
+    std::vector<uint32_t> order(chunk_count);
+    for (uint32_t i = 0; i < chunk_count; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return chunk_vD[a] > chunk_vD[b]; });
+    std::vector<std::vector<uint32_t>> shard(num_gpus);
+    std::vector<uint64_t> load(num_gpus, 0);
+    for (uint32_t ci : order) {
+        int best = 0;
+        for (int g = 1; g < num_gpus; ++g) if (load[g] < load[best]) best = g;
+        shard[best].push_back(ci);
+        load[best] += chunk_vD[ci];
+    }
+    const uint64_t stride = vect_sequences_db_count * vl;
+    std::vector<std::string> errs(num_gpus);
+    std::vector<std::thread> th;
+    for (int g = 0; g < num_gpus; ++g) {
+        th.emplace_back([&, g]() {   // one host thread per device, as MICsearch.c:53
+            if (shard[g].empty()) return;
+            swimm_hip_ctx *ctx = nullptr;
+            auto bail = [&]() { errs[g] = swimm_hip_last_error(); if (ctx) swimm_hip_destroy(ctx); };
+            if (swimm_hip_create(g, &ctx)) return bail();
+            if (swimm_hip_set_queries(ctx, query_sequences, query_sequences_lengths, query_disp, query_sequences_count,
+                                      submat, open_gap, extend_gap)) return bail();
+            for (uint32_t ci : shard[g])
+                if (swimm_hip_add_chunk(ctx, chunk_b[ci], chunk_vD[ci], chunk_n[ci], chunk_b_disp[ci],
+                                        chunk_vect_sequences_db_count[ci], vl, accum[ci])) return bail();
+            if (swimm_hip_search(ctx, scores, stride, nullptr)) return bail();
+            swimm_hip_destroy(ctx);
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int g = 0; g < num_gpus; ++g)
+        if (!errs[g].empty()) return fail("GPU %d: %s", g, errs[g].c_str());
+    if (workTime) *workTime = now_s() - t0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""GPU parity tests proper: HIP path (through the C-ABI) vs golden vectors and vs the CPU oracle.
+Bit-exact: these are integer scores."""
+import numpy as np
+import pytest
+
+from conftest import load_npy
+from helpers import golden_inputs, load_chunks, make_chunks, matrix
+from oracle import port
+from swimm_amd import hip_backend, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def searcher():
+    s = hip_backend.HipSearcher(0)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def gin(tmp_path_factory, golden):
+    return golden_inputs(tmp_path_factory.mktemp("gpu"), golden, vl=128)
+
+
+def _run(searcher, q, chunked, vl, sm, go, ge):
+    searcher.clear_db()
+    searcher.set_queries(q["a"], q["m"], q["disp"], sm, go, ge)
+    vc = load_chunks(searcher, chunked, vl)
+    scores, wt = searcher.search(vc * vl)
+    return scores
+
+
+def test_golden_all_cases(searcher, gin, golden):
+    """every matrix / gap fixture; includes multi-pass (3200-row query) and the int32 promotion tier"""
+    q, pp, chunked = gin
+    N = golden["search"]["n_sequences"]
+    for name, c in golden["search"]["cases"].items():
+        sc = _run(searcher, q, chunked, 128, matrix(c["matrix"]), c["open"], c["extend"])
+        want = load_npy(f"scores_{name}.npy")
+        assert np.array_equal(sc[:, :N], want), name
+        st = searcher.last_stats()
+        assert st["promoted"] > 0, "W x 3200 self hit must go through the int32 tier"
+
+
+@pytest.mark.parametrize("opts", [{"force_i32": 1}, {"rows_per_wave": 16}, {"max_waves": 1}, {"max_waves": 5, "wgs_per_cu": 1}])
+def test_golden_kernel_variants(gin, golden, opts):
+    q, pp, chunked = gin
+    N = golden["search"]["n_sequences"]
+    with hip_backend.HipSearcher(0) as s:
+        for k, v in opts.items():
+            s.set_option(k, v)
+        sc = _run(s, q, chunked, 128, matrix("blosum62"), 10, 2)
+    assert np.array_equal(sc[:, :N], load_npy("scores_blosum62_g10_e2.npy"))
+
+
+@pytest.mark.parametrize("vl,max_chunk", [(16, 20000), (32, 50000), (64, None), (128, 30000)])
+def test_reference_chunk_layouts(searcher, tmp_path, golden, vl, max_chunk):
+    """the boundary accepts the reference's own chunk layout for any lane width dividing 128"""
+    q, pp, chunked = golden_inputs(tmp_path, golden, vl=vl, max_chunk=max_chunk)
+    N = golden["search"]["n_sequences"]
+    sc = _run(searcher, q, chunked, vl, matrix("pam250"), 10, 2)
+    assert np.array_equal(sc[:, :N], load_npy("scores_pam250_g10_e2.npy"))
+
+
+def test_seeded_db_vs_oracle(searcher):
+    """5 000 log-normal sequences x 3 queries vs the exact CPU restatement"""
+    qs = synth.make_queries(5, [97, 375, 1000])
+    db = synth.make_db(5, synth.lengths_lognormal(5, 5000, 250, 0.7, 5, 4000), planted=synth.planted_homologs(5, qs), with_titles=False)
+    order = port.stable_sort_by_length(db.lengths)
+    offs = np.concatenate([[0], np.cumsum(db.lengths)])
+    lens = db.lengths[order]
+    codes = np.concatenate([port.recode(db.letters[offs[i]:offs[i + 1]]) for i in order])
+    qa = [port.recode(s) for _, s in qs]
+    m = np.array([len(x) for x in qa], dtype=np.uint16)
+    disp = np.concatenate([[0], np.cumsum(m)]).astype(np.uint32)
+    a = np.concatenate(qa)
+    chunked = make_chunks(lens, codes, 128, 200000)
+    sm = matrix("blosum50")
+    searcher.clear_db()
+    searcher.set_queries(a, m, disp, sm, 10, 2)
+    vc = load_chunks(searcher, chunked, 128)
+    got, _ = searcher.search(vc * 128)
+    one = port.assemble_single_chunk(lens, codes, 128, 5)
+    want = port.search_exact(a, m, disp, one["b"], one["n"], one["disp"], sm, 10, 2, 128)
+    assert np.array_equal(got, want)
+    # top-r through the ABI == the reference's sorted listing order
+    n = len(lens)
+    ts, ti, _ = searcher.search_topr(25, n)
+    for qi in range(3):
+        s, i = port.topr(want[qi, :n], 25)
+        assert np.array_equal(ts[qi], s) and np.array_equal(ti[qi], i)
+
+
+def test_search_chunks_dropin(tmp_path, golden):
+    q, pp, chunked = golden_inputs(tmp_path, golden, vl=16, max_chunk=20000)
+    N = golden["search"]["n_sequences"]
+    sc, wt = hip_backend.search_chunks(q["a"], q["m"], q["disp"], chunked["vc"], chunked["chunks"], matrix("blosum62"), 10, 2, 1, 16)
+    assert np.array_equal(sc[:, :N], load_npy("scores_blosum62_g10_e2.npy")) and wt > 0
+
+
+def test_errors_are_loud():
+    with hip_backend.HipSearcher(0) as s:
+        with pytest.raises(hip_backend.SwimmHipError):
+            s.search(128)  # nothing set
+        with pytest.raises(hip_backend.SwimmHipError):
+            s.set_queries(np.zeros(4, np.int8), np.array([4], np.uint16), np.array([0, 4], np.uint32), np.zeros(768, np.int8), 100, 100)
+        with pytest.raises(hip_backend.SwimmHipError):
+            s.add_chunk(np.zeros(48, np.int8), np.array([1], np.uint16), np.array([0], np.uint32), 48, 0)

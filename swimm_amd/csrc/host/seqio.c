@@ -1,0 +1,380 @@
+/* seqio.c -- FASTA input, preprocessed-database files, query batch (see swimm_host.h). */
+#define _GNU_SOURCE
+#include "swimm_host.h"
+
+#include <ctype.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+static __thread char g_err[512];
+
+const char *swimm_host_last_error(void) { return g_err; }
+
+int swimm_host_fail_(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define FAIL swimm_host_fail_
+
+double swimm_wtime(void)
+{
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return tv.tv_sec + tv.tv_usec / 1000000.0;
+}
+
+/* alphabet: A0 B1 C2 D3 E4 F5 G6 H7 I8 K9 L10 M11 N12 P13 Q14 R15 S16 T17 V18 W19 X20 Y21 Z22, J/O/U -> 23
+ * (sequences.c:164-175: J,O,U -> 'Z'+1, then letters above J / O / U shift down by 1 / 2 / 3) */
+static signed char g_code[256];
+static int g_code_ready;
+static void init_codes(void)
+{
+    if (g_code_ready) return;
+    for (int c = 0; c < 256; ++c) g_code[c] = SWIMM_DUMMY_CODE;
+    int next = 0;
+    for (int c = 'A'; c <= 'Z'; ++c) {
+        if (c == 'J' || c == 'O' || c == 'U') continue;
+        g_code[c] = (signed char)next;
+        g_code[tolower(c)] = (signed char)next;
+        next++;
+    }
+    g_code_ready = 1;
+}
+
+void swimm_recode(char *s, size_t n)
+{
+    init_codes();
+    for (size_t i = 0; i < n; ++i) s[i] = g_code[(unsigned char)s[i]];
+}
+
+/* ---- FASTA ------------------------------------------------------------------------------ */
+
+static int read_whole(const char *path, char **buf, size_t *len)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening input sequence file '%s'.", path);
+    if (fseeko(f, 0, SEEK_END) != 0) { fclose(f); return FAIL(SWIMM_E_FILE, "SWIMM: cannot seek in '%s'.", path); }
+    off_t sz = ftello(f);
+    rewind(f);
+    char *b = (char *)malloc((size_t)sz + 2);
+    if (!b) { fclose(f); return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory for sequences."); }
+    size_t got = fread(b, 1, (size_t)sz, f);
+    fclose(f);
+    if (got != (size_t)sz) { free(b); return FAIL(SWIMM_E_FILE, "SWIMM: short read on '%s'.", path); }
+    b[got] = '\n';   /* sentinel: the last line always ends */
+    b[got + 1] = 0;
+    *buf = b;
+    *len = got + 1;
+    return SWIMM_OK;
+}
+
+int swimm_fasta_read(const char *path, swimm_fasta *out)
+{
+    memset(out, 0, sizeof *out);
+    char *buf = NULL;
+    size_t len = 0;
+    int rc = read_whole(path, &buf, &len);
+    if (rc) return rc;
+    /* pass 1: count records */
+    uint64_t count = 0;
+    for (size_t i = 0; i < len;) {
+        if (buf[i] == '>') count++;
+        char *nl = (char *)memchr(buf + i, '\n', len - i);
+        i = (size_t)(nl - buf) + 1;
+    }
+    char *seqbuf = (char *)malloc(len + 1);
+    char **titles = (char **)malloc((count + 1) * sizeof(char *));
+    char **seqs = (char **)malloc((count + 1) * sizeof(char *));
+    uint32_t *lengths = (uint32_t *)malloc((count + 1) * sizeof(uint32_t));
+    if (!seqbuf || !titles || !seqs || !lengths) {
+        free(buf); free(seqbuf); free(titles); free(seqs); free(lengths);
+        return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory for sequences.");
+    }
+    /* pass 2: titles stay in the file buffer (newline -> NUL), residues are compacted into seqbuf */
+    uint64_t k = 0, total = 0;
+    size_t w = 0;
+    int in_record = 0;
+    for (size_t i = 0; i < len;) {
+        char *nl = (char *)memchr(buf + i, '\n', len - i);
+        size_t e = (size_t)(nl - buf);
+        if (buf[i] == '>') {
+            size_t te = e;
+            while (te > i && buf[te - 1] == '\r') te--;
+            buf[te] = 0;
+            titles[k] = buf + i;
+            seqs[k] = seqbuf + w;
+            lengths[k] = 0;
+            k++;
+            in_record = 1;
+        } else if (in_record) {
+            for (size_t j = i; j < e; ++j) {
+                unsigned char ch = (unsigned char)buf[j];
+                if (ch == '\r' || ch == ' ' || ch == '\t') continue;
+                seqbuf[w++] = (char)ch;
+                lengths[k - 1]++;
+                total++;
+            }
+        }
+        i = e + 1;
+    }
+    out->count = count;
+    out->residues = total;
+    out->titles = titles;
+    out->seqs = seqs;
+    out->lengths = lengths;
+    /* arena_: both big buffers are released through one pointer pair */
+    out->arena_ = buf;
+    seqs[count] = seqbuf;   /* remember the residue buffer's base for free() */
+    return SWIMM_OK;
+}
+
+void swimm_fasta_free(swimm_fasta *f)
+{
+    if (!f) return;
+    if (f->seqs) free(f->seqs[f->count]);
+    free(f->arena_);
+    free(f->titles);
+    free(f->seqs);
+    free(f->lengths);
+    memset(f, 0, sizeof *f);
+}
+
+/* stable ascending order by length: counting sort (same order as the reference's merge sort, which
+ * takes the left element on <=, sequences.c:780) */
+static uint64_t *stable_length_order(const uint32_t *lengths, uint64_t n)
+{
+    uint64_t *cnt = (uint64_t *)calloc(65537, sizeof(uint64_t));
+    uint64_t *order = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+    if (!cnt || !order) { free(cnt); free(order); return NULL; }
+    for (uint64_t i = 0; i < n; ++i) cnt[lengths[i] + 1]++;
+    for (int l = 0; l < 65536; ++l) cnt[l + 1] += cnt[l];
+    for (uint64_t i = 0; i < n; ++i) order[cnt[lengths[i]]++] = i;
+    free(cnt);
+    return order;
+}
+
+static int check_lengths(const swimm_fasta *f, const char *what)
+{
+    for (uint64_t i = 0; i < f->count; ++i)
+        if (f->lengths[i] > 65535)
+            return FAIL(SWIMM_E_FORMAT, "SWIMM: %s sequence %llu ('%.60s') has %u residues; the format stores lengths in 16 bits (max 65535).",
+                        what, (unsigned long long)i, f->titles[i], f->lengths[i]);
+    return SWIMM_OK;
+}
+
+int swimm_preprocess_db(const char *fasta_path, const char *out_prefix, uint64_t *n_sequences, uint64_t *n_residues)
+{
+    swimm_fasta f;
+    int rc = swimm_fasta_read(fasta_path, &f);
+    if (rc) return rc;
+    if (f.count == 0) { swimm_fasta_free(&f); return FAIL(SWIMM_E_FORMAT, "SWIMM: '%s' holds no FASTA record.", fasta_path); }
+    if ((rc = check_lengths(&f, "database"))) { swimm_fasta_free(&f); return rc; }
+    uint64_t *order = stable_length_order(f.lengths, f.count);
+    if (!order) { swimm_fasta_free(&f); return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); }
+    char name[4096];
+    size_t max_title = 0;
+    /* .desc : title lines (with '>') in sorted order, sequences.c:128-141 */
+    snprintf(name, sizeof name, "%s.desc", out_prefix);
+    FILE *fd = fopen(name, "wb");
+    if (!fd) { free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening sequence header file."); }
+    for (uint64_t i = 0; i < f.count; ++i) {
+        const char *t = f.titles[order[i]];
+        size_t tl = strlen(t);
+        if (tl > max_title) max_title = tl;
+        fwrite(t, 1, tl, fd);
+        fputc('\n', fd);
+    }
+    fclose(fd);
+    /* .info : "%ld %ld %d", no newline; max title = longest line incl. '>' + newline + 1 (sequences.c:36,187) */
+    snprintf(name, sizeof name, "%s.info", out_prefix);
+    FILE *fi = fopen(name, "wb");
+    if (!fi) { free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening info file."); }
+    fprintf(fi, "%ld %ld %d", (long)f.count, (long)f.residues, (int)(max_title + 2));
+    fclose(fi);
+    /* .seq : uint16 lengths, then recoded residues, both in sorted order (sequences.c:201-205) */
+    snprintf(name, sizeof name, "%s.seq", out_prefix);
+    FILE *fs = fopen(name, "wb");
+    if (!fs) { free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening sequence file."); }
+    uint16_t *l16 = (uint16_t *)malloc(f.count * sizeof(uint16_t));
+    if (!l16) { fclose(fs); free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); }
+    for (uint64_t i = 0; i < f.count; ++i) l16[i] = (uint16_t)f.lengths[order[i]];
+    fwrite(l16, sizeof(uint16_t), f.count, fs);
+    free(l16);
+    for (uint64_t i = 0; i < f.count; ++i) {
+        uint64_t s = order[i];
+        swimm_recode(f.seqs[s], f.lengths[s]);
+        fwrite(f.seqs[s], 1, f.lengths[s], fs);
+    }
+    int werr = ferror(fs);
+    fclose(fs);
+    if (n_sequences) *n_sequences = f.count;
+    if (n_residues) *n_residues = f.residues;
+    free(order);
+    swimm_fasta_free(&f);
+    if (werr) return FAIL(SWIMM_E_FILE, "SWIMM: write error on '%s.seq'.", out_prefix);
+    return SWIMM_OK;
+}
+
+/* ---- preprocessed database ------------------------------------------------------------ */
+
+int swimm_db_load(const char *prefix, swimm_db *out)
+{
+    memset(out, 0, sizeof *out);
+    char name[4096];
+    snprintf(name, sizeof name, "%s.info", prefix);
+    FILE *fi = fopen(name, "r");
+    if (!fi) return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening info file.");
+    long cnt = 0, D = 0;
+    int mt = 0;
+    int got = fscanf(fi, "%ld %ld %d", &cnt, &D, &mt);
+    fclose(fi);
+    if (got != 3 || cnt <= 0 || D < 0) return FAIL(SWIMM_E_FORMAT, "SWIMM: '%s' is not a valid info file.", name);
+    snprintf(name, sizeof name, "%s.seq", prefix);
+    FILE *fs = fopen(name, "rb");
+    if (!fs) return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening sequence file.");
+    uint16_t *lengths = (uint16_t *)malloc((size_t)cnt * sizeof(uint16_t));
+    char *codes = (char *)malloc((size_t)D + 1);
+    if (!lengths || !codes) { fclose(fs); free(lengths); free(codes); return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); }
+    size_t g1 = fread(lengths, sizeof(uint16_t), (size_t)cnt, fs);
+    size_t g2 = fread(codes, 1, (size_t)D, fs);
+    fclose(fs);
+    if (g1 != (size_t)cnt || g2 != (size_t)D) { free(lengths); free(codes); return FAIL(SWIMM_E_FORMAT, "SWIMM: '%s' is truncated.", name); }
+    uint64_t sum = 0;
+    for (long i = 0; i < cnt; ++i) {
+        sum += lengths[i];
+        if (i && lengths[i] < lengths[i - 1]) { free(lengths); free(codes); return FAIL(SWIMM_E_FORMAT, "SWIMM: '%s' is not sorted by length.", name); }
+    }
+    if (sum != (uint64_t)D) { free(lengths); free(codes); return FAIL(SWIMM_E_FORMAT, "SWIMM: lengths in '%s' do not add up to %ld residues.", name, D); }
+    for (long i = 0; i < D; ++i)
+        if ((unsigned char)codes[i] > SWIMM_DUMMY_CODE) { free(lengths); free(codes); return FAIL(SWIMM_E_FORMAT, "SWIMM: residue code %d in '%s' is outside 0..23.", codes[i], name); }
+    out->count = (uint64_t)cnt;
+    out->residues = (uint64_t)D;
+    out->max_title_length = mt;
+    out->lengths = lengths;
+    out->codes = codes;
+    return SWIMM_OK;
+}
+
+void swimm_db_free(swimm_db *db)
+{
+    if (!db) return;
+    free(db->lengths);
+    free(db->codes);
+    memset(db, 0, sizeof *db);
+}
+
+typedef struct { int64_t line; uint64_t pos; } want_t;
+static int want_cmp(const void *a, const void *b)
+{
+    int64_t x = ((const want_t *)a)->line, y = ((const want_t *)b)->line;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+int swimm_db_titles(const char *prefix, uint64_t count, const int64_t *idx, uint64_t n_idx, char **titles_out)
+{
+    char name[4096];
+    snprintf(name, sizeof name, "%s.desc", prefix);
+    FILE *f = fopen(name, "rb");
+    if (!f) return FAIL(SWIMM_E_DESC, "SWIMM: An error occurred while opening sequence description file.");
+    want_t *w = (want_t *)malloc((n_idx ? n_idx : 1) * sizeof(want_t));
+    if (!w) { fclose(f); return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); }
+    for (uint64_t i = 0; i < n_idx; ++i) {
+        if (idx[i] < 0 || (uint64_t)idx[i] >= count) { free(w); fclose(f); return FAIL(SWIMM_E_ARG, "SWIMM: title index %lld outside the database.", (long long)idx[i]); }
+        w[i].line = idx[i];
+        w[i].pos = i;
+        titles_out[i] = NULL;
+    }
+    qsort(w, n_idx, sizeof(want_t), want_cmp);
+    char *line = NULL;
+    size_t cap = 0;
+    int64_t ln = 0;
+    uint64_t k = 0;
+    ssize_t got;
+    while (k < n_idx && (got = getline(&line, &cap, f)) >= 0) {
+        if (ln == w[k].line) {
+            while (got > 0 && (line[got - 1] == '\n' || line[got - 1] == '\r')) line[--got] = 0;
+            const char *t = line[0] == '>' ? line + 1 : line;
+            while (k < n_idx && w[k].line == ln) titles_out[w[k++].pos] = strdup(t);
+        }
+        ln++;
+    }
+    free(line);
+    free(w);
+    fclose(f);
+    if (k < n_idx) return FAIL(SWIMM_E_DESC, "SWIMM: '%s' has fewer than %llu lines.", name, (unsigned long long)count);
+    return SWIMM_OK;
+}
+
+/* ---- queries -------------------------------------------------------------------------- */
+
+int swimm_queries_load(const char *fasta_path, int pad_even, swimm_queries *out)
+{
+    memset(out, 0, sizeof *out);
+    swimm_fasta f;
+    int rc = swimm_fasta_read(fasta_path, &f);
+    if (rc) return rc;
+    if (f.count == 0) { swimm_fasta_free(&f); return FAIL(SWIMM_E_FORMAT, "SWIMM: '%s' holds no FASTA record.", fasta_path); }
+    if ((rc = check_lengths(&f, "query"))) { swimm_fasta_free(&f); return rc; }
+    for (uint64_t i = 0; i < f.count; ++i) {
+        if (f.lengths[i] == 0) {
+            rc = FAIL(SWIMM_E_FORMAT, "SWIMM: query %llu ('%.60s') is empty.", (unsigned long long)i, f.titles[i]);
+            swimm_fasta_free(&f);
+            return rc;
+        }
+        if (pad_even && f.lengths[i] == 65535) { swimm_fasta_free(&f); return FAIL(SWIMM_E_FORMAT, "SWIMM: query %llu cannot be even-padded past 65535.", (unsigned long long)i); }
+    }
+    uint64_t *order = stable_length_order(f.lengths, f.count);
+    uint64_t Q = 0, tbytes = 0;
+    for (uint64_t i = 0; i < f.count; ++i) {
+        Q += f.lengths[i] + (pad_even ? (f.lengths[i] & 1) : 0);
+        tbytes += strlen(f.titles[i]) + 1;
+    }
+    char *a = (char *)malloc(Q + 64);
+    uint16_t *m = (uint16_t *)malloc(f.count * sizeof(uint16_t));
+    uint16_t *real = (uint16_t *)malloc(f.count * sizeof(uint16_t));
+    uint32_t *disp = (uint32_t *)malloc((f.count + 1) * sizeof(uint32_t));
+    char **titles = (char **)malloc(f.count * sizeof(char *));
+    char *arena = (char *)malloc(tbytes + 1);
+    if (!order || !a || !m || !real || !disp || !titles || !arena) {
+        free(order); free(a); free(m); free(real); free(disp); free(titles); free(arena);
+        swimm_fasta_free(&f);
+        return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory for query sequences.");
+    }
+    uint64_t pos = 0, tp = 0;
+    for (uint64_t k = 0; k < f.count; ++k) {
+        uint64_t s = order[k];
+        uint32_t L = f.lengths[s];
+        disp[k] = (uint32_t)pos;
+        memcpy(a + pos, f.seqs[s], L);
+        swimm_recode(a + pos, L);
+        real[k] = (uint16_t)L;
+        m[k] = (uint16_t)L;
+        if (pad_even && (L & 1)) { a[pos + L] = SWIMM_DUMMY_CODE; m[k]++; }   /* sequences.c:382-385 */
+        pos += m[k];
+        size_t tl = strlen(f.titles[s]) + 1;
+        memcpy(arena + tp, f.titles[s], tl);
+        titles[k] = arena + tp;
+        tp += tl;
+    }
+    disp[f.count] = (uint32_t)pos;
+    out->count = f.count;
+    out->Q = Q;
+    out->a = a; out->m = m; out->lengths = real; out->disp = disp; out->titles = titles; out->arena_ = arena;
+    free(order);
+    swimm_fasta_free(&f);
+    return SWIMM_OK;
+}
+
+void swimm_queries_free(swimm_queries *q)
+{
+    if (!q) return;
+    free(q->a); free(q->m); free(q->lengths); free(q->disp); free(q->titles); free(q->arena_);
+    memset(q, 0, sizeof *q);
+}

@@ -58,4 +58,9 @@ hipError_t launch_flag_saturated(const int32_t *scores, uint64_t n, uint8_t *fla
 // scores[slot*64 + lane] = 0 for the listed half-groups (before the int32 rerun's atomicMax)
 hipError_t launch_reset_halves(int32_t *scores, const uint32_t *half_slots, uint32_t count, hipStream_t s);
 
+// per-block top-64 candidates of one query's score row: out_keys[block*64 + i] = ((score<<32 | global index) + 1),
+// 0 = empty; group_base[g] = global sorted index of the group's first sequence, group_valid[g] = real sequences in it
+hipError_t launch_topk64(const int32_t *scores, uint64_t n_slots, const int64_t *group_base, const uint32_t *group_valid,
+                         unsigned long long *out_keys, int n_blocks, hipStream_t s);
+
 }  // namespace swimm

@@ -337,4 +337,88 @@ hipError_t launch_reset_halves(int32_t *scores, const uint32_t *half_slots, uint
     return hipGetLastError();
 }
 
+
+// ---- device top-r candidates ------------------------------------------------------------------
+// Replaces sort_scores + the print loop's first r rows (utils.c:71-86, swimm.c:151-160) for r <= 64:
+// key = (score << 32) | global sorted index, so "larger key first" is exactly the reference order
+// (score descending, ties by LARGER index first, utils.c:12,52).  Every wave keeps the 64 largest
+// keys it has seen, one per lane in descending order; a tile of 64 new keys is merged in only when
+// a wave-wide ballot finds one above the current 64th key (wavefront __shfl_xor bitonic network).
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask)
+{
+    const unsigned lo = __shfl_xor((unsigned)v, mask, 64), hi = __shfl_xor((unsigned)(v >> 32), mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src)
+{
+    const unsigned lo = __shfl((unsigned)v, src, 64), hi = __shfl((unsigned)(v >> 32), src, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// sort 64 keys (one per lane) descending
+__device__ __forceinline__ unsigned long long wave_sort_desc(unsigned long long v, int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned long long o = shfl_xor_u64(v, j);
+            const bool desc = (lane & k) == 0;          // direction of this k-block (k == 64: all descending)
+            const bool lower = (lane & j) == 0;         // lower lane of the pair keeps the larger key when descending
+            const bool take_max = (desc == lower);
+            v = take_max ? (v > o ? v : o) : (v < o ? v : o);
+        }
+    }
+    return v;
+}
+// both sorted descending -> the 64 largest of the union, sorted descending
+__device__ __forceinline__ unsigned long long wave_merge_desc(unsigned long long a, unsigned long long b, int lane)
+{
+    const unsigned long long br = shfl_u64(b, 63 - lane);
+    unsigned long long v = a > br ? a : br;             // bitonic sequence holding the top 64
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const unsigned long long o = shfl_xor_u64(v, j);
+        const bool lower = (lane & j) == 0;
+        v = lower ? (v > o ? v : o) : (v < o ? v : o);
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256) topk64_kernel(const int32_t *__restrict__ scores, uint64_t n_slots,
+                                                     const int64_t *__restrict__ group_base,
+                                                     const uint32_t *__restrict__ group_valid,
+                                                     unsigned long long *__restrict__ out_keys)
+{
+    __shared__ unsigned long long sh[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long top = 0;                          // key 0 = empty (real keys have index >= 0, score >= 0: key 0 only for (0, 0), handled by +1 below)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x + (uint64_t)wv * 64; base < n_slots; base += stride) {
+        const uint64_t slot = base + lane;
+        unsigned long long key = 0;
+        if (slot < n_slots) {
+            const uint32_t g = (uint32_t)(slot >> 7), off = (uint32_t)(slot & 127);
+            if (off < group_valid[g]) {
+                const unsigned long long idx = (unsigned long long)(group_base[g] + off);
+                key = (((unsigned long long)(uint32_t)scores[slot]) << 32 | idx) + 1;   // +1: keep 0 as "empty"
+            }
+        }
+        const unsigned long long kth = shfl_u64(top, 63);
+        if (__ballot(key > kth) != 0ull) top = wave_merge_desc(top, wave_sort_desc(key, lane), lane);
+    }
+    sh[wv][lane] = top;
+    __syncthreads();
+    if (wv == 0) {
+        for (int w = 1; w < 4; ++w) top = wave_merge_desc(top, sh[w][lane], lane);
+        out_keys[(size_t)blockIdx.x * 64 + lane] = top;
+    }
+}
+
+hipError_t launch_topk64(const int32_t *scores, uint64_t n_slots, const int64_t *group_base, const uint32_t *group_valid,
+                         unsigned long long *out_keys, int n_blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(topk64_kernel, dim3(n_blocks), dim3(256), 0, s, scores, n_slots, group_base, group_valid, out_keys);
+    return hipGetLastError();
+}
+
 }  // namespace swimm

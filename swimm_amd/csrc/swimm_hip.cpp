@@ -110,6 +110,9 @@ struct swimm_hip_ctx {
     DevBuf<uint2> d_bnd;
     DevBuf<uint8_t> d_flags;
     DevBuf<uint32_t> d_slots;
+    DevBuf<int64_t> d_gbase;
+    DevBuf<uint32_t> d_gvalid;
+    DevBuf<unsigned long long> d_keys;
     // stats of the last search
     double kernel_ms = 0;
     uint64_t cells = 0, promoted = 0;
@@ -396,7 +399,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
     c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
-    c->d_flags.release(); c->d_slots.release();
+    c->d_flags.release(); c->d_slots.release(); c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -537,11 +540,50 @@ int swimm_hip_search_topr(swimm_hip_ctx *c, uint32_t r, uint64_t n_valid, int32_
     uint64_t S = 0;
     if (search_device(c, &S)) return 1;
     const uint32_t qn = (uint32_t)c->qm.size();
+    typedef std::pair<int32_t, int64_t> Hit;   // larger pair first == score desc, then larger index first (utils.c:12,52)
+    if (r <= 64) {
+        // device path: per-block top-64 candidate keys, final selection over n_blocks*64 keys on the host
+        std::vector<int64_t> gbase(c->groups.size());
+        std::vector<uint32_t> gvalid(c->groups.size());
+        for (const ChunkRec &ch : c->chunks)
+            for (uint32_t i = 0; i < ch.n_groups; ++i) {
+                const uint64_t first = ch.first_seq + (uint64_t)i * kGroupSeqs;
+                uint64_t cnt = (uint64_t)i * kGroupSeqs < ch.n_seq ? std::min<uint64_t>(kGroupSeqs, ch.n_seq - (uint64_t)i * kGroupSeqs) : 0;
+                if (first >= n_valid) cnt = 0; else cnt = std::min<uint64_t>(cnt, n_valid - first);
+                gbase[ch.group0 + i] = (int64_t)first;
+                gvalid[ch.group0 + i] = (uint32_t)cnt;
+            }
+        const int n_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(256, S / 1024));
+        HIP_TRY(c->d_gbase.reserve(gbase.size()));
+        HIP_TRY(c->d_gvalid.reserve(gvalid.size()));
+        HIP_TRY(c->d_keys.reserve((size_t)qn * n_blocks * 64));
+        HIP_TRY(hipMemcpyAsync(c->d_gbase.p, gbase.data(), gbase.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_gvalid.p, gvalid.data(), gvalid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        for (uint32_t q = 0; q < qn; ++q)
+            HIP_TRY(launch_topk64(c->d_scores.p + (size_t)q * S, S, c->d_gbase.p, c->d_gvalid.p,
+                                  c->d_keys.p + (size_t)q * n_blocks * 64, n_blocks, c->stream));
+        std::vector<unsigned long long> keys((size_t)qn * n_blocks * 64);
+        HIP_TRY(hipMemcpyAsync(keys.data(), c->d_keys.p, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (uint32_t q = 0; q < qn; ++q) {
+            unsigned long long *kq = keys.data() + (size_t)q * n_blocks * 64;
+            const size_t nk = (size_t)n_blocks * 64;
+            const size_t k = std::min<size_t>(r, nk);
+            std::partial_sort(kq, kq + k, kq + nk, std::greater<unsigned long long>());
+            for (uint32_t i = 0; i < r; ++i) {
+                const bool have = i < k && kq[i] != 0;
+                const unsigned long long key = have ? kq[i] - 1 : 0;
+                top_scores[(size_t)q * r + i] = have ? (int32_t)(key >> 32) : -1;
+                top_index[(size_t)q * r + i] = have ? (int64_t)(key & 0xFFFFFFFFull) : -1;
+            }
+        }
+        if (work_time) *work_time = now_s() - t0;
+        return 0;
+    }
+    // r > 64: whole score rows come back and the host selects (heap, O(N log r))
     std::vector<int32_t> host((size_t)qn * S);
     HIP_TRY(hipMemcpyAsync(host.data(), c->d_scores.p, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    // key = (score, global index): larger key first == score desc, then larger index first (utils.c:12,52)
-    typedef std::pair<int32_t, int64_t> Hit;
     std::vector<Hit> hits;
     for (uint32_t q = 0; q < qn; ++q) {
         hits.clear();

@@ -86,9 +86,15 @@ def test_seeded_db_vs_oracle(searcher):
     assert np.array_equal(got, want)
     # top-r through the ABI == the reference's sorted listing order
     n = len(lens)
-    ts, ti, _ = searcher.search_topr(25, n)
+    for r in (1, 25, 64, 100):   # <= 64: device wave-shuffle top-r; > 64: host selection
+        ts, ti, _ = searcher.search_topr(r, n)
+        for qi in range(3):
+            s, i = port.topr(want[qi, :n], r)
+            assert np.array_equal(ts[qi], s) and np.array_equal(ti[qi], i), (r, qi)
+    # n_valid below the resident count: padding / excluded lanes never show up
+    ts, ti, _ = searcher.search_topr(10, n - 77)
     for qi in range(3):
-        s, i = port.topr(want[qi, :n], 25)
+        s, i = port.topr(want[qi, :n - 77], 10)
         assert np.array_equal(ts[qi], s) and np.array_equal(ti[qi], i)
 
 

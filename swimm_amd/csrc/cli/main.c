@@ -1,0 +1,203 @@
+/* main.c -- the `swimm` program: `-S preprocess` and `-S search` (reference: swimm.c:9-207).
+ *
+ * Same command line, same preprocessed-database files, same report text; the search itself runs on
+ * MI355X GPUs through libswimm_hip.so (dlopen, include/swimm_hip.h) in the default mode 1, or on the
+ * host CPU when mode 0 is asked for explicitly.  Structure of the GPU path follows
+ * mic_search_knc_ap_multiple_chunks (MICsearch.c:53-346): one host thread per device, each device
+ * gets its chunks, queries and matrix are replicated, results are merged on the host -- except that
+ * the chunk-to-device assignment is static (longest-first onto the least-loaded GPU) and only the
+ * top-r rows per query come back instead of every score.
+ */
+#define _GNU_SOURCE
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../host/swimm_host.h"
+#include "hip_loader.h"
+#include "options.h"
+
+static void die_host(int status)
+{
+    printf("%s\n", swimm_host_last_error());
+    /* exit codes of the reference: 1 memory, 2 files, 3 description file (sequences.c:16-19,54,748-751) */
+    exit(status == SWIMM_E_NOMEM ? 1 : status == SWIMM_E_FILE ? 2 : status == SWIMM_E_DESC ? 3 : 4);
+}
+
+static int do_preprocess(const swimm_options *o)
+{
+    const double tick = swimm_wtime();
+    uint64_t n = 0, d = 0;
+    int rc = swimm_preprocess_db(o->input_filename, o->output_filename, &n, &d);
+    if (rc) die_host(rc);
+    printf("\nSWIMM v%s\n\n", SWIMM_VERSION);
+    printf("Database file:\t\t\t %s\n", o->input_filename);
+    printf("Database size:\t\t\t%ld sequences (%ld residues) \n", (long)n, (long)d);
+    printf("Preprocessed database name:\t%s\n", o->output_filename);
+    printf("Preprocessing time:\t\t%lf seconds\n\n", swimm_wtime() - tick);
+    return 0;
+}
+
+/* static shard: chunks longest-first onto the least-loaded GPU (cost = padded bytes) */
+static void shard_chunks(const swimm_chunks *ch, int gpus, int *owner)
+{
+    uint64_t *load = (uint64_t *)calloc((size_t)gpus, sizeof(uint64_t));
+    uint32_t *order = (uint32_t *)malloc(ch->chunk_count * sizeof(uint32_t));
+    for (uint32_t i = 0; i < ch->chunk_count; ++i) order[i] = i;
+    for (uint32_t i = 1; i < ch->chunk_count; ++i) {   /* insertion sort, stable, descending vD */
+        uint32_t x = order[i];
+        int64_t j = (int64_t)i - 1;
+        while (j >= 0 && ch->chunk_vD[order[j]] < ch->chunk_vD[x]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = x;
+    }
+    for (uint32_t k = 0; k < ch->chunk_count; ++k) {
+        int best = 0;
+        for (int g = 1; g < gpus; ++g) if (load[g] < load[best]) best = g;
+        owner[order[k]] = best;
+        load[best] += ch->chunk_vD[order[k]];
+    }
+    free(load);
+    free(order);
+}
+
+int main(int argc, char **argv)
+{
+    swimm_options o;
+    swimm_parse_options(argc, argv, &o);
+    if (strcmp(o.op, "preprocess") == 0) return do_preprocess(&o);
+
+    time_t current_time = time(NULL);
+    printf("\nSWIMM v%s \n\n", SWIMM_VERSION);
+    printf("Database file:\t\t\t%s\n", o.db_prefix);
+
+    const char *submat = swimm_submat(o.submat_name);
+    const int gpu_mode = o.execution_mode == MODE_GPU_ONLY;
+    if (o.cpu_block_size == 0) o.cpu_block_size = (o.vector_length == 32 ? 64 : 128) / SWIMM_SEQ_LEN_MULT * SWIMM_SEQ_LEN_MULT;   /* swimm.c:32-35 */
+
+    /* mode 0 pads odd queries to even length (sequences.c:378-387); the accelerator mode does not (347-364) */
+    swimm_queries q;
+    int rc = swimm_queries_load(o.queries_filename, gpu_mode ? 0 : 1, &q);
+    if (rc) die_host(rc);
+    swimm_db db;
+    if ((rc = swimm_db_load(o.db_prefix, &db))) die_host(rc);
+    unsigned long top = db.count < o.top ? db.count : o.top;   /* swimm.c:51 */
+
+    printf("Database size:\t\t\t%ld sequences (%ld residues) \n", (long)db.count, (long)db.residues);
+    printf("Longest database sequence: \t%d residues\n", (int)db.lengths[db.count - 1]);
+    printf("Substitution matrix:\t\t%s\n", swimm_submat_label(o.submat_name));
+    printf("Gap open penalty:\t\t%d\n", o.open_gap);
+    printf("Gap extend penalty:\t\t%d\n", o.extend_gap);
+    printf("Query filename:\t\t\t%s\n", o.queries_filename);
+    fflush(stdout);
+
+    int32_t *top_scores = (int32_t *)malloc(q.count * top * sizeof(int32_t));
+    int64_t *top_idx = (int64_t *)malloc(q.count * top * sizeof(int64_t));
+    if (!top_scores || !top_idx) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
+    double workTime = 0, kernel_ms = 0;
+    uint64_t promoted = 0;
+    uint32_t chunk_count = 0;
+    omp_set_num_threads(o.cpu_threads);
+
+    if (!gpu_mode) {
+        swimm_single_chunk sc;
+        if ((rc = swimm_assemble_single_chunk(db.lengths, db.codes, db.count, o.vector_length, o.cpu_block_size, &sc))) die_host(rc);
+        const uint64_t stride = sc.vc * (uint64_t)o.vector_length;
+        int32_t *scores = (int32_t *)malloc(q.count * stride * sizeof(int32_t));
+        if (!scores) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
+        if ((rc = swimm_cpu_search(q.a, q.m, q.count, q.disp, sc.b, sc.n, sc.vc, sc.disp, submat, o.open_gap, o.extend_gap,
+                                   o.cpu_threads, o.cpu_block_size, o.vector_length, scores, &workTime))) die_host(rc);
+        for (uint64_t i = 0; i < q.count; ++i)   /* sort_scores + first `top` rows, swimm.c:151-160 */
+            swimm_topr(scores + i * stride, db.count, (uint32_t)top, top_scores + i * top, top_idx + i * top);
+        free(scores);
+        swimm_single_chunk_free(&sc);
+    } else {
+        swimm_hip_api api;
+        char err[1024];
+        if (swimm_hip_load(&api, err, sizeof err)) { printf("%s\n", err); exit(5); }
+        const int avail = api.device_count();
+        if (avail <= 0) { printf("SWIMM: no MI355X visible: %s\n", api.last_error()); exit(5); }
+        if (o.num_gpus > avail) { printf("SWIMM: %d GPUs requested, %d visible.\n", o.num_gpus, avail); exit(5); }
+        swimm_chunks ch;
+        if ((rc = swimm_assemble_chunks(db.lengths, db.codes, db.count, 128, o.max_chunk_size, &ch))) die_host(rc);
+        chunk_count = ch.chunk_count;
+        const int G = o.num_gpus;
+        int *owner = (int *)malloc(ch.chunk_count * sizeof(int));
+        shard_chunks(&ch, G, owner);
+        int32_t *part_s = (int32_t *)malloc((size_t)G * q.count * top * sizeof(int32_t));
+        int64_t *part_i = (int64_t *)malloc((size_t)G * q.count * top * sizeof(int64_t));
+        char (*gerr)[512] = calloc((size_t)G, 512);
+        double *g_kms = (double *)calloc((size_t)G, sizeof(double));
+        uint64_t *g_prom = (uint64_t *)calloc((size_t)G, sizeof(uint64_t));
+        for (size_t i = 0; i < (size_t)G * q.count * top; ++i) { part_s[i] = -1; part_i[i] = -1; }
+        const double tick = swimm_wtime();   /* brackets transfers + kernels + merge, like MICsearch.c:51,350 */
+#pragma omp parallel num_threads(G)
+        {
+            const int g = omp_get_thread_num();
+            swimm_hip_ctx *ctx = NULL;
+            int mine = 0;
+            for (uint32_t c = 0; c < ch.chunk_count; ++c) mine += owner[c] == g;
+            int bad = 0;
+            if (mine == 0) bad = -1;   /* nothing to do on this device */
+            if (!bad && api.create(g, &ctx)) bad = 1;
+            if (!bad && api.set_queries(ctx, q.a, q.m, q.disp, (uint32_t)q.count, submat, o.open_gap, o.extend_gap)) bad = 1;
+            for (uint32_t c = 0; !bad && c < ch.chunk_count; ++c)
+                if (owner[c] == g && api.add_chunk(ctx, ch.chunk_b[c], ch.chunk_vD[c], ch.chunk_n[c], ch.chunk_disp[c],
+                                                   ch.chunk_groups[c], 128, ch.chunk_first_group[c])) bad = 1;
+            if (!bad && api.search_topr(ctx, (uint32_t)top, db.count, part_s + (size_t)g * q.count * top,
+                                        part_i + (size_t)g * q.count * top, NULL)) bad = 1;
+            if (bad > 0) snprintf(gerr[g], 512, "%s", api.last_error());
+            if (!bad) api.last_stats(ctx, &g_kms[g], NULL, &g_prom[g], NULL);
+            if (ctx) api.destroy(ctx);
+        }
+        for (int g = 0; g < G; ++g) if (gerr[g][0]) { printf("SWIMM: GPU %d: %s\n", g, gerr[g]); exit(5); }
+        /* host k-way merge of the per-GPU lists: per query, lists are [G][top] */
+        int32_t *ls = (int32_t *)malloc((size_t)G * top * sizeof(int32_t));
+        int64_t *li = (int64_t *)malloc((size_t)G * top * sizeof(int64_t));
+        for (uint64_t i = 0; i < q.count; ++i) {
+            for (int g = 0; g < G; ++g) {
+                memcpy(ls + (size_t)g * top, part_s + ((size_t)g * q.count + i) * top, top * sizeof(int32_t));
+                memcpy(li + (size_t)g * top, part_i + ((size_t)g * q.count + i) * top, top * sizeof(int64_t));
+            }
+            swimm_topr_merge(ls, li, (uint32_t)G, (uint32_t)top, top_scores + i * top, top_idx + i * top);
+        }
+        workTime = swimm_wtime() - tick;
+        for (int g = 0; g < G; ++g) { if (g_kms[g] > kernel_ms) kernel_ms = g_kms[g]; promoted += g_prom[g]; }
+        free(ls); free(li); free(part_s); free(part_i); free(gerr); free(g_kms); free(g_prom); free(owner);
+        swimm_chunks_free(&ch);
+    }
+
+    /* titles of the reported hits only (the reference loads all N, sequences.c:757-761) */
+    char **titles = (char **)malloc(q.count * top * sizeof(char *));
+    if ((rc = swimm_db_titles(o.db_prefix, db.count, top_idx, q.count * top, titles))) die_host(rc);
+    for (uint64_t i = 0; i < q.count; ++i) {
+        printf("\nQuery no.\t\t\t%d\n", (int)i + 1);
+        printf("Query description: \t\t%s\n", q.titles[i] + 1);
+        printf("Query length:\t\t\t%d residues\n", q.lengths[i]);
+        printf("\nScore\tSequence description\n");
+        for (unsigned long j = 0; j < top; ++j) printf("%d\t%s\n", top_scores[i * top + j], titles[i * top + j]);
+    }
+    /* GCUPS as the reference prints it: Q (as stored: even-padded in mode 0, real in mode 1) x D / time, swimm.c:163 */
+    printf("\nSearch date:\t\t\t%s", ctime(&current_time));
+    printf("Search time:\t\t\t%lf seconds\n", workTime);
+    printf("Search speed:\t\t\t%.2lf GCUPS\n", ((double)q.Q * (double)db.residues) / (workTime * 1000000000));
+    if (!gpu_mode) {
+        printf("Execution mode:\t\t\tHost CPU only (%d threads, block width = %d)\n", o.cpu_threads, o.cpu_block_size);
+        printf("Profile technique:\t\tSubstitution row per query residue\n");
+        printf("Instruction set:\t\tcompiler-vectorised int32 lanes (vector length = %d)\n", o.vector_length);
+    } else {
+        printf("Execution mode:\t\t\tMI355X only (%d GPUs)\n", o.num_gpus);
+        printf("Profile technique:\t\tQuery Profile in LDS\n");
+        printf("Instruction set:\t\tgfx950 packed int16, int32 promotion (vector length = 128)\n");
+        printf("Max. chunk size:\t\t%ld bytes\n", o.max_chunk_size);
+        printf("Chunk count:\t\t\t%ld \n", (long)chunk_count);
+        printf("Kernel time:\t\t\t%lf seconds\n", kernel_ms / 1000.0);
+        printf("Promoted to int32:\t\t%ld alignments\n", (long)promoted);
+    }
+    for (uint64_t i = 0; i < q.count * top; ++i) free(titles[i]);
+    free(titles); free(top_scores); free(top_idx);
+    swimm_db_free(&db);
+    swimm_queries_free(&q);
+    return 0;
+}

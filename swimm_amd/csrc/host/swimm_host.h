@@ -122,6 +122,12 @@ void swimm_topr(const int32_t *scores, uint64_t n, uint32_t r, int32_t *out_scor
 void swimm_topr_merge(const int32_t *scores, const int64_t *idx, uint32_t lists, uint32_t r, int32_t *out_scores,
                       int64_t *out_idx);
 
+/* ---- execution mode 0: search on the host CPU, same arguments as cpu_search_avx2_sp (CPUsearch.h:37-39)
+ * plus the lane width `vl` the database was assembled with; scores[(q*vc + s)*vl + lane]. ---- */
+int swimm_cpu_search(const char *a, const uint16_t *m, uint64_t query_count, const uint32_t *a_disp, const char *b,
+                     const uint16_t *n, uint64_t vc, const uint64_t *b_disp, const char *submat, int open_gap,
+                     int extend_gap, int n_threads, int block_size, int vl, int32_t *scores, double *work_time);
+
 /* ---- substitution tables (submat.c:4-227): 768 bytes [query_code*32 + db_code], or NULL ---- */
 const char *swimm_submat(const char *name);
 const char *swimm_submat_label(const char *name);

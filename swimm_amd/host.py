@@ -19,7 +19,7 @@ HOST_SYMBOLS = (
     "swimm_host_last_error", "swimm_recode", "swimm_fasta_read", "swimm_fasta_free", "swimm_preprocess_db",
     "swimm_db_load", "swimm_db_free", "swimm_db_titles", "swimm_queries_load", "swimm_queries_free",
     "swimm_assemble_single_chunk", "swimm_single_chunk_free", "swimm_assemble_chunks", "swimm_chunks_free",
-    "swimm_topr", "swimm_topr_merge", "swimm_submat", "swimm_submat_label", "swimm_wtime",
+    "swimm_topr", "swimm_topr_merge", "swimm_cpu_search", "swimm_submat", "swimm_submat_label", "swimm_wtime",
 )
 
 
@@ -184,6 +184,21 @@ class Chunks:
             self.close()
         except Exception:
             pass
+
+
+def cpu_search(a, m, a_disp, b, n, b_disp, submat_tbl, open_gap, extend_gap, vl, threads=1, block_size=60):
+    """execution mode 0 (explicit host-CPU search); argument order of cpu_search_avx2_sp + vl.
+    -> (scores int32 [q, vc*vl], work_time)"""
+    a = np.ascontiguousarray(a, dtype=np.int8); m = np.ascontiguousarray(m, dtype=np.uint16)
+    a_disp = np.ascontiguousarray(a_disp, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.int8)
+    n = np.ascontiguousarray(n, dtype=np.uint16); b_disp = np.ascontiguousarray(b_disp, dtype=np.uint64)
+    sm = np.ascontiguousarray(submat_tbl, dtype=np.int8)
+    scores = np.zeros((len(m), len(n) * vl), dtype=np.int32)
+    wt = C.c_double()
+    _check(lib().swimm_cpu_search(_p(a), _p(m), C.c_uint64(len(m)), _p(a_disp), _p(b), _p(n), C.c_uint64(len(n)), _p(b_disp),
+                                  _p(sm), C.c_int(open_gap), C.c_int(extend_gap), C.c_int(threads), C.c_int(block_size),
+                                  C.c_int(vl), _p(scores), C.byref(wt)))
+    return scores, wt.value
 
 
 def topr(scores, r: int):

@@ -1,0 +1,123 @@
+"""The `swimm` program: flag surface, file formats and report text (reference: swimm.c, arguments.c).
+Mode 0 (explicit host-CPU search) runs here; mode 1 (MI355X) is exercised by the gpu-marked test."""
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_npy
+from swimm_amd import host, submat
+
+SWIMM = os.path.join(ROOT, "swimm_amd", "bin", "swimm")
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def run(*args, check=True):
+    p = subprocess.run([SWIMM, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if check:
+        assert p.returncode == 0, p.stdout + p.stderr
+    return p
+
+
+@pytest.fixture(scope="module")
+def dbprefix(tmp_path_factory, golden):
+    prefix = str(tmp_path_factory.mktemp("cli") / "db")
+    p = run("-S", "preprocess", "-i", os.path.join(GOLDEN, golden["db_fasta"]), "-o", prefix)
+    assert "Database size:\t\t\t413 sequences (84979 residues) \n" in p.stdout
+    return prefix
+
+
+def test_preprocess_files(dbprefix, golden):
+    g = golden["preprocess"]
+    assert sha(open(dbprefix + ".seq", "rb").read()) == g["seq_sha256"]
+    assert open(dbprefix + ".info").read() == g["info"]
+    assert sha(open(dbprefix + ".desc", "rb").read()) == g["desc_clean_sha256"]
+
+
+def parse_report(text):
+    """-> list of (query title, length, [(score, title)])"""
+    out = []
+    for blk in re.split(r"\nQuery no\.\t\t\t\d+\n", text)[1:]:
+        desc = re.search(r"Query description: \t\t(.*)\n", blk).group(1)
+        length = int(re.search(r"Query length:\t\t\t(\d+) residues\n", blk).group(1))
+        body = blk.split("\nScore\tSequence description\n")[1].split("\nSearch date:")[0]
+        hits = [(int(l.split("\t", 1)[0]), l.split("\t", 1)[1]) for l in body.split("\n") if "\t" in l]
+        out.append((desc, length, hits))
+    return out
+
+
+def check_listing(text, golden, dbprefix, case, r):
+    sc, order = load_npy(f"scores_{case}.npy"), load_npy(f"order_{case}.npy")
+    titles = [l[1:] for l in open(dbprefix + ".desc").read().split("\n")]
+    rep = parse_report(text)
+    gq = golden["queries"]["mode0"]
+    assert [t for t, _, _ in rep] == [t[1:] for t in gq["titles"]]
+    assert [L for _, L, _ in rep] == gq["lengths"]          # unpadded lengths are printed
+    for qi, (_, _, hits) in enumerate(rep):
+        assert len(hits) == r
+        assert [s for s, _ in hits] == sc[qi][order[qi][:r]].tolist()
+        assert [t for _, t in hits] == [titles[i] for i in order[qi][:r]]   # includes the tie order
+
+
+def test_search_mode0_full_listing(dbprefix, golden):
+    """every row of the reference's sorted listing (-r N), BLOSUM62 and PAM250, both lane widths"""
+    q = os.path.join(GOLDEN, golden["query_fasta"])
+    p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "0", "-v", "32", "-c", "4", "-r", "413")
+    check_listing(p.stdout, golden, dbprefix, "blosum62_g10_e2", 413)
+    assert "Substitution matrix:\t\tBLOSUM62\n" in p.stdout and "Gap open penalty:\t\t10\n" in p.stdout
+    assert re.search(r"Search speed:\t\t\t\d+\.\d\d GCUPS\n", p.stdout)
+    p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "0", "-v", "16", "-b", "35", "-c", "3", "-s", "pam250", "-r", "1000")
+    check_listing(p.stdout, golden, dbprefix, "pam250_g10_e2", 413)   # top = min(N, r), swimm.c:51
+    p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "0", "-s", "pam30", "-g", "12", "-e", "3")
+    check_listing(p.stdout, golden, dbprefix, "pam30_g12_e3", 10)      # default -r 10, -v 16
+
+
+def test_cpu_search_library_all_cases(dbprefix, golden):
+    db = host.db_load(dbprefix)
+    q = host.queries_load(os.path.join(GOLDEN, golden["query_fasta"]), True)
+    N = golden["search"]["n_sequences"]
+    for vl, blk in ((32, 60), (16, 125), (128, 20)):
+        one = host.assemble_single_chunk(db["lengths"], db["codes"], vl, blk)
+        for name, c in golden["search"]["cases"].items():
+            sc, wt = host.cpu_search(q["a"], q["m"], q["disp"], one["b"], one["n"], one["disp"], submat.table(c["matrix"]),
+                                     c["open"], c["extend"], vl, threads=4, block_size=blk)
+            assert np.array_equal(sc[:, :N], load_npy(f"scores_{name}.npy")), (vl, name)
+
+
+def test_flag_validation(dbprefix, golden):
+    q = os.path.join(GOLDEN, golden["query_fasta"])
+    assert run("-S", "search", "-q", q, "-d", dbprefix, "-m", "2", check=False).returncode == 1   # hybrid not built
+    assert run("-S", "search", "-q", q, "-d", dbprefix, "-s", "blosum99", check=False).returncode == 1
+    assert run("-S", "search", "-q", q, "-d", dbprefix, "-g", "100", "-e", "100", check=False).returncode == 1
+    assert run("-S", "search", "-q", q, "-d", dbprefix, "-v", "64", "-m", "0", check=False).returncode == 1
+    assert run("-S", "frobnicate", check=False).returncode == 1
+    assert run("-S", "search", "-q", q, check=False).returncode == 1
+    p = run("-S", "search", "-q", q, "-d", dbprefix + "_missing", "-m", "0", check=False)
+    assert p.returncode == 2 and "SWIMM: An error occurred while opening info file." in p.stdout
+    p = run("-S", "preprocess", "-i", "/nonexistent.fa", "-o", "/tmp/x", check=False)
+    assert p.returncode == 2
+
+
+def test_gpu_mode_fails_loudly_without_backend(dbprefix, golden, tmp_path):
+    """mode 1 with no usable back-end is an error, never a CPU fallback"""
+    q = os.path.join(GOLDEN, golden["query_fasta"])
+    env = dict(os.environ, SWIMM_HIP_LIB=str(tmp_path / "nope.so"))
+    p = subprocess.run([SWIMM, "-S", "search", "-q", q, "-d", dbprefix, "-m", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert p.returncode == 5 and "cannot load the MI355X back-end" in p.stdout
+    assert "Query no." not in p.stdout
+
+
+@pytest.mark.gpu
+def test_search_mode1_gpu_listing(dbprefix, golden):
+    q = os.path.join(GOLDEN, golden["query_fasta"])
+    p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-x", "1", "-r", "30", "-k", "30000")
+    check_listing(p.stdout, golden, dbprefix, "blosum62_g10_e2", 30)
+    assert "Execution mode:\t\t\tMI355X only (1 GPUs)\n" in p.stdout and "Promoted to int32:\t\t64 alignments\n" in p.stdout
+    p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-r", "413", "-s", "blosum50")   # r > 64: host selection path
+    check_listing(p.stdout, golden, dbprefix, "blosum50_g10_e2", 413)

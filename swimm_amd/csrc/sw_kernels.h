@@ -43,6 +43,36 @@ struct PipeParams {
 
 enum class Mode { PK16, I32 };
 
+// ---- lane-systolic kernel: ONE wave aligns one packed pair (or one sequence in int32 mode) with its 64
+// lanes as the query strips; used for the long-sequence tail and for the int32 promotion re-runs, where
+// a whole 128-sequence group on one workgroup would be a serial chain.
+constexpr int kLaneRows = 8;                  // query rows per lane -> 512 rows per pass
+struct LaneItem {
+    const uint8_t *db;     // tiled residues of the item's device group
+    uint32_t lane;         // which lane's dword pair of that group (0..63)
+    uint32_t half;         // int32 mode: 0 = sequence A of the pair, 1 = B
+    uint32_t ncols;        // multiple of kChunkCols
+    uint32_t slot_a;       // score slot of A (packed) / of the sequence (int32)
+    uint32_t slot_b;       // score slot of B (packed only)
+    uint32_t bnd_off;      // first column of this item in the pass-boundary buffer
+    uint32_t pad_;
+};
+struct LaneParams {
+    const LaneItem *items;
+    uint32_t n_items;
+    uint32_t *queue;            // work cursor, zeroed before every launch
+    const int16_t *prof;
+    uint32_t prof_stride;
+    uint32_t r0;                // first query row of this pass
+    uint32_t rows;              // real query rows in this pass (<= 64 * kLaneRows)
+    uint2 *bnd;
+    int first_pass, last_pass;
+    int32_t *out;
+    int goe, ge;
+};
+size_t lane_lds_bytes();
+hipError_t launch_lane(Mode mode, int n_wg, const LaneParams &p, hipStream_t s);
+
 size_t pipe_lds_bytes(int rows_per_wave, int waves);
 // registers / occupancy of one instantiation (for the host-side launch plan)
 hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, int *num_regs);

@@ -265,6 +265,155 @@ hipError_t pipe_kernel_attributes(Mode mode, int T, int *num_regs)
     return e;
 }
 
+// ---- lane-systolic kernel ------------------------------------------------------------------------
+// Same recurrence, other axis of parallelism: the 64 lanes of ONE wave are 64 consecutive strips of
+// kLaneRows query rows of the SAME alignment (two database sequences packed per register in int16 mode,
+// one in int32 mode).  Lane l works on column j - l; after every column the strip's bottom row
+// (H, F), the column's residues + start/end flags, the running best and the item / column ids move
+// one lane to the right with v_mov_b32_dpp wave_shr:1 (lane 0 takes the next column instead).
+// Items stream through the lanes back to back, so the 64-step skew is paid once per wave, not per
+// sequence.  One alignment is spread over a whole wave instead of sharing a wave with 127 others:
+// a 35 000-residue sequence is a chain of 35 000 short steps on its own wave, and the few dozen
+// such chains of a Swiss-Prot-shaped database run side by side instead of serially on one CU.
+__device__ __forceinline__ uint32_t dpp_shr1(uint32_t prev, uint32_t lane0_value)
+{
+    // lanes 1..63 <- prev of lane-1 ; lane 0 keeps `lane0_value` (no source lane, bound_ctrl off)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)prev, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+
+constexpr uint32_t kFlagStart = 1u << 16, kFlagEnd = 1u << 17, kFlagReal = 1u << 18;   // kFlagReal: a column of an item (not pipeline fill/drain)
+
+size_t lane_lds_bytes() { return round16((size_t)kCodes * prof_row_bytes(64 * kLaneRows)); }
+
+template <bool PK>
+__global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
+{
+    typedef typename std::conditional<PK, OpsPK, OpsI32>::type Ops;
+    typedef typename Ops::V V;
+    constexpr int TR = kLaneRows, C = kChunkCols, RP = 64 * TR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int PS = prof_row_bytes(RP);
+    {
+        const int dw_per_code = RP >> 1;
+        for (int idx = threadIdx.x; idx < kCodes * dw_per_code; idx += blockDim.x) {
+            const int d = idx / dw_per_code, x = idx - d * dw_per_code;
+            const uint32_t *src = (const uint32_t *)(p.prof + (size_t)d * p.prof_stride + p.r0);
+            *(uint32_t *)(smem + d * PS + x * 4) = src[x];
+        }
+    }
+    __syncthreads();
+    const unsigned char *my_prof = smem + lane * TR * 2;
+    const int last_lane = (int)((p.rows + TR - 1) / TR) - 1;      // lane holding the query's last rows in this pass
+    const V goe = Ops::splat(p.goe), ge = Ops::splat(p.ge);
+
+    V H[TR], E[TR];
+#pragma unroll
+    for (int r = 0; r < TR; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+    V best = Ops::zero(), diag = Ops::zero();
+    uint32_t oH = 0, oF = 0, oD = 0x1818u, oT = 0, oS = 0, oC = 0;   // what this lane hands to lane+1
+
+    bool feeding = true;
+    int drained = 0;
+    uint32_t item = 0, cc = 0, nch = 0, it_lane = 0, it_half = 0, it_bnd = 0;
+    const uint8_t *it_db = nullptr;
+
+    for (;;) {
+        if (feeding && cc == nch) {                // wave-uniform: pull the next item
+            uint32_t idx = 0;
+            if (lane == 0) idx = atomicAdd(p.queue, 1u);
+            idx = __builtin_amdgcn_readfirstlane(idx);
+            if (idx >= p.n_items) {
+                feeding = false;
+            } else {
+                const LaneItem iv = p.items[idx];
+                item = idx; cc = 0; nch = iv.ncols / C; it_db = iv.db; it_lane = iv.lane; it_half = iv.half; it_bnd = iv.bnd_off;
+            }
+        }
+        uint32_t wa = 0x18181818u, wb = 0x18181818u;   // pad residues (code 24) while draining
+        uint2 b4[C];
+#pragma unroll
+        for (int jj = 0; jj < C; ++jj) b4[jj] = make_uint2(0u, 0u);
+        if (feeding) {
+            const uint2 w = *(const uint2 *)(it_db + ((size_t)cc * 64 + it_lane) * 8);   // uniform address
+            wa = PK ? w.x : (it_half ? w.y : w.x);
+            wb = w.y;
+            if (!p.first_pass) {
+#pragma unroll
+                for (int jj = 0; jj < C; ++jj) b4[jj] = p.bnd[(size_t)it_bnd + cc * C + jj];
+            }
+        } else {
+            if (drained >= 64) break;             // every lane has seen the last real column
+            drained += C;
+        }
+#pragma unroll
+        for (int jj = 0; jj < C; ++jj) {
+            uint32_t d0 = (wa >> (8 * jj)) & 0xffu;
+            if (PK) d0 |= ((wb >> (8 * jj)) & 0xffu) << 8;
+            if (feeding) d0 |= kFlagReal;
+            if (feeding && cc == 0 && jj == 0) d0 |= kFlagStart;
+            if (feeding && cc + 1 == nch && jj == C - 1) d0 |= kFlagEnd;
+            const uint32_t col0 = it_bnd + cc * C + jj;
+            // hand-over: every lane takes its left neighbour's column, lane 0 the next one
+            const uint32_t D = dpp_shr1(oD, d0);
+            const uint32_t Hin = dpp_shr1(oH, b4[jj].x), Fin = dpp_shr1(oF, b4[jj].y);
+            const uint32_t Tin = dpp_shr1(oT, 0u), Sin = dpp_shr1(oS, item), Cin = dpp_shr1(oC, col0);
+            if (D & kFlagStart) {                 // first column of an alignment reaches this lane
+#pragma unroll
+                for (int r = 0; r < TR; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+                best = Ops::zero(); diag = Ops::zero();
+            }
+            const unsigned char *pa = my_prof + (D & 0xffu) * PS;
+            V hd = diag;
+            diag = Ops::from_bits(Hin);
+            V F = Ops::from_bits(Fin);
+            const uint4 a = *(const uint4 *)pa;
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+            if (PK) {
+                const unsigned char *pb = my_prof + ((D >> 8) & 0xffu) * PS;
+                const uint4 b = *(const uint4 *)pb;
+                const uint32_t bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cell<Ops>(hd, H[2 * q], E[2 * q], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)), goe, ge);
+                    cell<Ops>(hd, H[2 * q + 1], E[2 * q + 1], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cell<Ops>(hd, H[2 * q], E[2 * q], F, best, Ops::from_bits((uint32_t)(int)(short)(aw[q] & 0xffffu)), goe, ge);
+                    cell<Ops>(hd, H[2 * q + 1], E[2 * q + 1], F, best, Ops::from_bits((uint32_t)((int)aw[q] >> 16)), goe, ge);
+                }
+            }
+            oH = Ops::bits(H[TR - 1]); oF = Ops::bits(F); oD = D; oS = Sin; oC = Cin; oT = Tin;
+            if (D & kFlagEnd) oT = Ops::bits(Ops::vmax(Ops::from_bits(Tin), best));   // running best of the alignment
+            if (lane == last_lane && (D & kFlagReal)) {   // fill / drain columns must never reach memory
+                if (!p.last_pass) p.bnd[Cin] = make_uint2(oH, oF);
+                if (D & kFlagEnd) {
+                    const LaneItem *iv = p.items + Sin;
+                    if (PK) {
+                        const v2s b2 = __builtin_bit_cast(v2s, oT);
+                        atomicMax(p.out + iv->slot_a, (int)b2.x);
+                        atomicMax(p.out + iv->slot_b, (int)b2.y);
+                    } else {
+                        atomicMax(p.out + iv->slot_a, (int)oT);
+                    }
+                }
+            }
+        }
+        if (feeding) ++cc;
+    }
+}
+
+hipError_t launch_lane(Mode mode, int n_wg, const LaneParams &p, hipStream_t s)
+{
+    if (n_wg < 1) return hipErrorInvalidValue;
+    const size_t lds = lane_lds_bytes();
+    if (mode == Mode::PK16) hipLaunchKernelGGL((sw_lane_kernel<true>), dim3(n_wg), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((sw_lane_kernel<false>), dim3(n_wg), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
 // ---- re-tile: reference chunk layout -> device groups --------------------------------------
 // reference byte of VL-group v, position j, lane kk: b[disp[v] + j*vl + kk]   (sequences.c:508-513)
 // device dword of group g, chunk c, lane l: tiled[goff[g] + (c*64 + l)*8 + {0: seq l, 4: seq 64+l}]

@@ -71,6 +71,22 @@ struct Plan {      // static partition of a work list over n_wg persistent workg
     void release() { items.release(); wg_first.release(); wg_chunks.release(); }
 };
 
+// lane-systolic work list (long-sequence tail, int32 promotion): items sorted longest first, pulled
+// dynamically by the waves
+struct LaneList {
+    DevBuf<LaneItem> items;
+    uint32_t n = 0;
+    uint64_t cols = 0;       // boundary columns (sum of ncols)
+    uint64_t cell_cols = 0;  // sum of ncols (for the cell statistics)
+    void release() { items.release(); n = 0; }
+};
+
+struct DbPlan {          // per (mode, n_wg): main partition + the groups handed to the lane kernel
+    Plan main;
+    bool have_main = false;
+    LaneList tail;
+};
+
 struct ChunkRec {
     uint8_t *d_tiled = nullptr;
     uint64_t first_seq = 0;     // global sorted index of the chunk's first sequence
@@ -89,6 +105,7 @@ struct swimm_hip_ctx {
     int num_cu = 0;
     // options
     int opt_T = 32, opt_maxW = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;
+    int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
     // queries (host copies; profiles are built per search because T/W may change)
     std::vector<int8_t> qcodes;
     std::vector<uint16_t> qm;
@@ -103,7 +120,7 @@ struct swimm_hip_ctx {
     uint64_t total_cols = 0;
     DevBuf<GroupDesc> d_groups;
     bool groups_dirty = true;
-    std::map<int, Plan> plans;          // key: n_wg (packed mode), n_wg | 1<<30 (whole-db int32 mode)
+    std::map<int, DbPlan> plans;        // key: n_wg (packed mode), n_wg | 1<<30 (whole-db int32 mode)
     // scratch
     DevBuf<int32_t> d_scores;
     DevBuf<int16_t> d_prof;
@@ -113,6 +130,7 @@ struct swimm_hip_ctx {
     DevBuf<int64_t> d_gbase;
     DevBuf<uint32_t> d_gvalid;
     DevBuf<unsigned long long> d_keys;
+    DevBuf<uint32_t> d_queue;
     // stats of the last search
     double kernel_ms = 0;
     uint64_t cells = 0, promoted = 0;
@@ -120,6 +138,12 @@ struct swimm_hip_ctx {
 };
 
 namespace {
+
+void release_plans(swimm_hip_ctx *c)
+{
+    for (auto &kv : c->plans) { kv.second.main.release(); kv.second.tail.release(); }
+    c->plans.clear();
+}
 
 int regs_to_waves_per_simd(int regs)
 {
@@ -200,31 +224,92 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
     return 0;
 }
 
-int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, Plan **out)
+int upload_lane_items(swimm_hip_ctx *c, std::vector<LaneItem> &v, LaneList &ll)
+{
+    std::stable_sort(v.begin(), v.end(), [](const LaneItem &a, const LaneItem &b) { return a.ncols > b.ncols; });
+    uint64_t cols = 0;
+    for (LaneItem &it : v) {
+        if (cols + it.ncols > 0xFFFFFFFFull) return fail("lane work list exceeds 2^32 boundary columns");
+        it.bnd_off = (uint32_t)cols;
+        cols += it.ncols;
+    }
+    ll.n = (uint32_t)v.size();
+    ll.cols = cols;
+    ll.cell_cols = cols;
+    HIP_TRY(ll.items.reserve(v.size()));
+    HIP_TRY(hipMemcpyAsync(ll.items.p, v.data(), v.size() * sizeof(LaneItem), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Which groups leave the workgroup pipeline for the lane-systolic kernel: a group is one serial chain on
+// one workgroup, so any group longer than a fraction of the mean per-workgroup load would set the
+// kernel's makespan (Swiss-Prot's 35 000-residue titin against a 360-residue mean).  Longest first, move
+// groups while ncols > tail_alpha * (remaining columns / n_wg).
+std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, int n_wg)
+{
+    std::vector<uint8_t> is_tail(c->groups.size(), 0);
+    if (c->opt_tail_mode == 2) return is_tail;                        // never
+    if (c->opt_tail_mode == 1) { std::fill(is_tail.begin(), is_tail.end(), 1); return is_tail; }   // always
+    std::vector<uint32_t> order(c->groups.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->groups[a].ncols > c->groups[b].ncols; });
+    uint64_t rest = c->total_cols;
+    for (uint32_t g : order) {
+        const double mean = (double)rest / n_wg;
+        if ((double)c->groups[g].ncols <= 0.5 * mean) break;
+        is_tail[g] = 1;
+        rest -= c->groups[g].ncols;
+    }
+    return is_tail;
+}
+
+int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, DbPlan **out)
 {
     const int key = n_wg | (mode == Mode::I32 ? (1 << 30) : 0);
     auto it = c->plans.find(key);
     if (it != c->plans.end()) { *out = &it->second; return 0; }
     std::vector<WorkUnit> units;
+    std::vector<LaneItem> tail;
     uint64_t bnd_cols = 0;
     if (mode == Mode::PK16) {
-        units.reserve(c->groups.size());
-        for (uint32_t g = 0; g < c->groups.size(); ++g)
-            units.push_back(WorkUnit{g, 0, 0, c->groups[g].ncols, c->group_col_off[g]});
+        const std::vector<uint8_t> is_tail = pick_tail(c, n_wg);
+        for (uint32_t g = 0; g < c->groups.size(); ++g) {
+            const GroupDesc &gd = c->groups[g];
+            if (!is_tail[g]) { units.push_back(WorkUnit{g, 0, 0, gd.ncols, c->group_col_off[g]}); continue; }
+            for (uint32_t l = 0; l < 64; ++l) {
+                LaneItem li{};
+                li.db = gd.db; li.lane = l; li.half = 0; li.ncols = gd.ncols; li.slot_a = gd.seq0 + l; li.slot_b = gd.seq0 + 64 + l;
+                tail.push_back(li);
+            }
+        }
         bnd_cols = c->total_cols;
     } else {
-        units.reserve(c->groups.size() * 2);
         for (uint32_t g = 0; g < c->groups.size(); ++g)
             for (uint32_t h = 0; h < 2; ++h)
                 units.push_back(WorkUnit{g, h, c->groups[g].seq0 / 64 + h, c->groups[g].ncols,
                                          2 * c->group_col_off[g] + (uint64_t)h * c->groups[g].ncols});
         bnd_cols = 2 * c->total_cols;
     }
-    Plan &pl = c->plans[key];
-    if (build_plan(c, units, n_wg, pl)) return 1;
-    pl.bnd_cols = bnd_cols;
-    *out = &pl;
+    DbPlan &dp = c->plans[key];
+    if (!units.empty()) {
+        if (build_plan(c, units, n_wg, dp.main)) return 1;
+        dp.main.bnd_cols = bnd_cols;
+        dp.have_main = true;
+    }
+    if (!tail.empty() && upload_lane_items(c, tail, dp.tail)) return 1;
+    *out = &dp;
     return 0;
+}
+
+void fill_common(const swimm_hip_ctx *c, const QueryPlan &qp, PipeParams &p)
+{
+    p.groups = c->d_groups.p;
+    p.prof = c->d_prof.p + qp.prof_off;
+    p.prof_stride = qp.mpad;
+    p.bnd = c->d_bnd.p;
+    p.goe = c->open_gap + c->extend_gap;
+    p.ge = c->extend_gap;
 }
 
 int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row)
@@ -232,22 +317,50 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
     if (qp.passes > 1) HIP_TRY(c->d_bnd.reserve(pl.bnd_cols * 64));
     for (int pass = 0; pass < qp.passes; ++pass) {
         PipeParams p{};
-        p.groups = c->d_groups.p;
+        fill_common(c, qp, p);
         p.items = pl.items.p;
         p.wg_first = pl.wg_first.p;
         p.wg_chunks = pl.wg_chunks.p;
-        p.prof = c->d_prof.p + qp.prof_off;
-        p.prof_stride = qp.mpad;
         p.r0 = (uint32_t)(pass * qp.W * qp.T);
-        p.bnd = c->d_bnd.p;
         p.first_pass = pass == 0;
         p.last_pass = pass == qp.passes - 1;
         p.out = out_row;
-        p.goe = c->open_gap + c->extend_gap;
-        p.ge = c->extend_gap;
         HIP_TRY(launch_pipe(mode, qp.T, qp.W, pl.n_wg, p, c->stream));
         c->launches++;
         c->cells += pl.total_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * (mode == Mode::PK16 ? 128 : 64);
+    }
+    return 0;
+}
+
+// all passes of the lane-systolic kernel over one work list for one query
+int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row)
+{
+    if (ll.n == 0) return 0;
+    const int rows_pass = 64 * kLaneRows;
+    const int passes = (m + rows_pass - 1) / rows_pass;
+    if (passes > 1) HIP_TRY(c->d_bnd.reserve(std::max<uint64_t>(ll.cols, 1)));
+    HIP_TRY(c->d_queue.reserve(1));
+    // 4 waves per workgroup; enough workgroups to fill the chip (58 VGPRs: 8 waves/SIMD, 26 KB LDS: 6 per CU)
+    const int n_wg = (int)std::max<uint64_t>(1, std::min<uint64_t>((ll.n + 3) / 4, (uint64_t)c->num_cu * 6));
+    for (int pass = 0; pass < passes; ++pass) {
+        LaneParams p{};
+        p.items = ll.items.p;
+        p.n_items = ll.n;
+        p.queue = c->d_queue.p;
+        p.prof = c->d_prof.p + qp.prof_off;
+        p.prof_stride = qp.mpad;
+        p.r0 = (uint32_t)(pass * rows_pass);
+        p.rows = (uint32_t)std::min(rows_pass, m - pass * rows_pass);
+        p.bnd = c->d_bnd.p;
+        p.first_pass = pass == 0;
+        p.last_pass = pass == passes - 1;
+        p.out = out_row;
+        p.goe = c->open_gap + c->extend_gap;
+        p.ge = c->extend_gap;
+        HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(launch_lane(mode, n_wg, p, c->stream));
+        c->launches++;
+        c->cells += ll.cell_cols * (uint64_t)rows_pass * (mode == Mode::PK16 ? 2 : 1);
     }
     return 0;
 }
@@ -258,8 +371,7 @@ int upload_groups(swimm_hip_ctx *c)
     HIP_TRY(c->d_groups.reserve(c->groups.size()));
     HIP_TRY(hipMemcpyAsync(c->d_groups.p, c->groups.data(), c->groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (auto &kv : c->plans) kv.second.release();
-    c->plans.clear();
+    release_plans(c);
     c->groups_dirty = false;
     return 0;
 }
@@ -277,11 +389,14 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     c->kernel_ms = 0; c->cells = 0; c->promoted = 0; c->launches = 0;
 
     // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
-    // transposed so that consecutive query rows are contiguous for one residue code)
+    // transposed so that consecutive query rows are contiguous for one residue code); rows past the
+    // query's end are zero, like the reference's dummy row 23
     std::vector<QueryPlan> qps(qn);
     size_t prof_elems = 0;
     for (uint32_t q = 0; q < qn; ++q) {
         qps[q] = choose_plan(c, c->qm[q]);
+        const uint32_t lane_rows = (uint32_t)((c->qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
+        qps[q].mpad = std::max(qps[q].mpad, lane_rows);
         qps[q].prof_off = prof_elems;
         prof_elems += (size_t)kCodes * qps[q].mpad;
     }
@@ -303,11 +418,15 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     for (uint32_t q = 0; q < qn; ++q) {
         int per_cu = 1;
         if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
-        Plan *pl = nullptr;
-        if (get_db_plan(c, main_mode, c->num_cu * per_cu, &pl)) return 1;
-        if (run_passes(c, main_mode, qps[q], *pl, c->d_scores.p + (size_t)q * S)) return 1;
+        DbPlan *dp = nullptr;
+        if (get_db_plan(c, main_mode, c->num_cu * per_cu, &dp)) return 1;
+        int32_t *row = c->d_scores.p + (size_t)q * S;
+        // long-sequence tail first (few long chains), then the bulk
+        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row)) return 1;
+        if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row)) return 1;
     }
-    // promotion: lanes whose int16 best saturated are recomputed in int32 (CPUsearch.c:820-957)
+    // promotion: sequences whose int16 best saturated are recomputed in int32 (CPUsearch.c:820-957), every
+    // one of them as its own lane-systolic item
     if (main_mode == Mode::PK16) {
         std::vector<uint8_t> flags(S / 64);
         for (uint32_t q = 0; q < qn; ++q) {
@@ -317,30 +436,30 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             HIP_TRY(launch_flag_saturated(row, S, c->d_flags.p, c->stream));
             HIP_TRY(hipMemcpyAsync(flags.data(), c->d_flags.p, S / 64, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            std::vector<WorkUnit> units;
+            std::vector<LaneItem> items;
             std::vector<uint32_t> slots;
-            uint64_t cols = 0;
             for (uint32_t g = 0; g < c->groups.size(); ++g)
                 for (uint32_t h = 0; h < 2; ++h) {
                     const uint32_t slot = c->groups[g].seq0 / 64 + h;
                     if (!flags[slot]) continue;
-                    units.push_back(WorkUnit{g, h, slot, c->groups[g].ncols, cols});
                     slots.push_back(slot);
-                    cols += c->groups[g].ncols;
+                    for (uint32_t l = 0; l < 64; ++l) {
+                        LaneItem li{};
+                        li.db = c->groups[g].db; li.lane = l; li.half = h; li.ncols = c->groups[g].ncols;
+                        li.slot_a = slot * 64 + l; li.slot_b = 0;
+                        items.push_back(li);
+                    }
                 }
-            if (units.empty()) continue;
-            c->promoted += units.size() * 64;
+            if (items.empty()) continue;
+            c->promoted += items.size();
             HIP_TRY(c->d_slots.reserve(slots.size()));
             HIP_TRY(hipMemcpyAsync(c->d_slots.p, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(launch_reset_halves(row, c->d_slots.p, (uint32_t)slots.size(), c->stream));
-            int per_cu = 1;
-            if (wgs_per_cu(c, Mode::I32, qps[q].T, qps[q].W, &per_cu)) return 1;
-            Plan pl;
-            if (build_plan(c, units, c->num_cu * per_cu, pl)) return 1;
-            pl.bnd_cols = cols;
-            const int rc = run_passes(c, Mode::I32, qps[q], pl, row);
+            LaneList ll;
+            if (upload_lane_items(c, items, ll)) return 1;
+            const int rc = run_lane_passes(c, Mode::I32, qps[q], c->qm[q], ll, row);
             if (rc == 0) HIP_TRY(hipStreamSynchronize(c->stream));
-            pl.release();
+            ll.release();
             if (rc) return 1;
         }
     }
@@ -399,7 +518,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
     c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
-    c->d_flags.release(); c->d_slots.release(); c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release();
+    c->d_flags.release(); c->d_slots.release(); c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_queue.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -504,8 +623,7 @@ int swimm_hip_clear_db(swimm_hip_ctx *c)
     for (auto &ch : c->chunks) (void)hipFree(ch.d_tiled);
     c->chunks.clear(); c->groups.clear(); c->group_col_off.clear();
     c->total_cols = 0;
-    for (auto &kv : c->plans) kv.second.release();
-    c->plans.clear();
+    release_plans(c);
     c->groups_dirty = true;
     return 0;
 }
@@ -626,11 +744,14 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         c->opt_maxW = value;
     } else if (!strcmp(key, "force_i32")) {
         c->opt_force_i32 = value != 0;
+    } else if (!strcmp(key, "tail_mode")) {
+        if (value < 0 || value > 2) return fail("tail_mode must be 0 (auto), 1 (all groups via the lane kernel) or 2 (none)");
+        c->opt_tail_mode = value;
+        release_plans(c);
     } else if (!strcmp(key, "wgs_per_cu")) {
         if (value < 0 || value > 16) return fail("wgs_per_cu must be 0..16");
         c->opt_wgs_per_cu = value;
-        for (auto &kv : c->plans) kv.second.release();
-        c->plans.clear();
+        release_plans(c);
     } else {
         return fail("swimm_hip_set_option: unknown key '%s'", key);
     }

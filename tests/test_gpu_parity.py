@@ -43,7 +43,8 @@ def test_golden_all_cases(searcher, gin, golden):
         assert st["promoted"] > 0, "W x 3200 self hit must go through the int32 tier"
 
 
-@pytest.mark.parametrize("opts", [{"force_i32": 1}, {"rows_per_wave": 16}, {"max_waves": 1}, {"max_waves": 5, "wgs_per_cu": 1}])
+@pytest.mark.parametrize("opts", [{"force_i32": 1}, {"rows_per_wave": 16}, {"max_waves": 1}, {"max_waves": 5, "wgs_per_cu": 1},
+                                  {"tail_mode": 1}, {"tail_mode": 2}, {"tail_mode": 1, "rows_per_wave": 16}])
 def test_golden_kernel_variants(gin, golden, opts):
     q, pp, chunked = gin
     N = golden["search"]["n_sequences"]

@@ -81,13 +81,10 @@ hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, int n_wg, const 
 // Re-tile one reference-layout chunk (sequences.c:506-526 byte interleave) into device groups.
 hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t vl_groups, uint32_t vl,
                          const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled,
-                         hipStream_t s);
+                         uint32_t *seq_len /* [dev_groups*128], zeroed; gets every sequence's true length */, hipStream_t s);
 
-// flags[i] = 1 if any of scores[i*64 .. i*64+63] >= 32767 (int16 tier saturated)
-hipError_t launch_flag_saturated(const int32_t *scores, uint64_t n, uint8_t *flags, hipStream_t s);
-// scores[slot*64 + lane] = 0 for the listed half-groups (before the int32 rerun's atomicMax)
-hipError_t launch_reset_halves(int32_t *scores, const uint32_t *half_slots, uint32_t count, hipStream_t s);
-
+// appends the slots whose int16 best saturated (>= 32767) to list (up to cap) and zeroes their scores
+hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s);
 // per-block top-64 candidates of one query's score row: out_keys[block*64 + i] = ((score<<32 | global index) + 1),
 // 0 = empty; group_base[g] = global sorted index of the group's first sequence, group_valid[g] = real sequences in it
 hipError_t launch_topk64(const int32_t *scores, uint64_t n_slots, const int64_t *group_base, const uint32_t *group_valid,

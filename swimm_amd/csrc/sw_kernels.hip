@@ -150,13 +150,14 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
             // database residues of this chunk: 4 columns of the lane's sequence(s)
             uint32_t wa, wb = 0;
             if (PK) {
-                const uint2 w = *(const uint2 *)(dbp + ((size_t)cc * 64 + lane) * 8);
-                wa = w.x; wb = w.y;
+                // dbp came out of a descriptor in memory: tell the compiler it is global memory (no flat_load)
+                const unsigned long long w = *(const __attribute__((address_space(1))) unsigned long long *)(uintptr_t)(dbp + ((size_t)cc * 64 + lane) * 8);
+                wa = (uint32_t)w; wb = (uint32_t)(w >> 32);
             } else {
-                wa = *(const uint32_t *)(dbp + ((size_t)cc * 64 + lane) * 8 + half * 4);
+                wa = *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)(dbp + ((size_t)cc * 64 + lane) * 8 + half * 4);
             }
             // top boundary of the strip for these columns: H of the row above, F entering row 0
-            uint2 bin[C], bout[C];
+            uint2 bin[C];
             if (k == 0) {
                 if (p.first_pass) {
 #pragma unroll
@@ -203,19 +204,13 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
                         }
                     }
                 }
-                bout[jj] = make_uint2(Ops::bits(H[T - 1]), Ops::bits(F));
+                // bottom boundary of this column: to the next wave through LDS, or (last wave, more passes) to HBM
+                const uint2 bout = make_uint2(Ops::bits(H[T - 1]), Ops::bits(F));
+                if (k < W - 1) ring[(size_t)((k * 2 + (c & 1)) * C + jj) * 64 + lane] = bout;
+                else if (!p.last_pass) p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = bout;
                 // keep one column's lookups in flight at a time: without this fence the scheduler hoists
                 // all four columns' LDS reads and the kernel needs ~230 VGPRs (spills at 3 waves/SIMD)
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            // bottom boundary: to the next wave through LDS, or (last wave, more passes) to HBM
-            if (k < W - 1) {
-                uint2 *dst = ring + (size_t)((k * 2 + (c & 1)) * C) * 64 + lane;
-#pragma unroll
-                for (int jj = 0; jj < C; ++jj) dst[jj * 64] = bout[jj];
-            } else if (!p.last_pass) {
-#pragma unroll
-                for (int jj = 0; jj < C; ++jj) p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = bout[jj];
             }
             if (++cc == nch) {   // item finished: every strip contributes its best (CPUsearch.c:670-676)
                 if (PK) {
@@ -285,6 +280,15 @@ constexpr uint32_t kFlagStart = 1u << 16, kFlagEnd = 1u << 17, kFlagReal = 1u <<
 
 size_t lane_lds_bytes() { return round16((size_t)kCodes * prof_row_bytes(64 * kLaneRows)); }
 
+// what lane 0 feeds into the pipeline for one chunk of 4 columns (wave-uniform)
+struct LaneFeed {
+    uint32_t wa, wb;        // residues of the 4 columns (sequence A / B)
+    uint2 b[kChunkCols];    // top boundary (H, F) of the 4 columns, zero in the first pass
+    uint32_t item, col0;    // item index, first column's index in the boundary buffer
+    uint32_t half;          // int32 mode: which of wa / wb is the sequence
+    uint32_t flags[kChunkCols];
+};
+
 template <bool PK>
 __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
 {
@@ -303,6 +307,7 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
         }
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(2);   // these waves are long serial chains: let them issue ahead of bulk waves on the same SIMD
     const unsigned char *my_prof = smem + lane * TR * 2;
     const int last_lane = (int)((p.rows + TR - 1) / TR) - 1;      // lane holding the query's last rows in this pass
     const V goe = Ops::splat(p.goe), ge = Ops::splat(p.ge);
@@ -311,15 +316,23 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
 #pragma unroll
     for (int r = 0; r < TR; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
     V best = Ops::zero(), diag = Ops::zero();
-    uint32_t oH = 0, oF = 0, oD = 0x1818u, oT = 0, oS = 0, oC = 0;   // what this lane hands to lane+1
+    // pipeline registers.  The residue stream (D) runs ONE step ahead of the boundary stream so that a lane
+    // can issue the profile reads of its next column before it computes the current one.
+    uint32_t oDn = 0x1818u;                  // residues this lane will hand to lane+1 (already one step ahead)
+    uint32_t Dcur = 0x1818u;                 // residues + flags of the column this lane computes in this step
+    uint4 acur = make_uint4(0, 0, 0, 0), bcur = make_uint4(0, 0, 0, 0);
+    uint32_t oH = 0, oF = 0, oT = 0, oS = 0, oC = 0;
+    uint2 pb = make_uint2(0u, 0u);           // boundary-side values of the column lane 0 fed one step ago
+    uint32_t pitem = 0, pcol = 0;
 
+    // producer state (wave-uniform): next chunk to feed
     bool feeding = true;
-    int drained = 0;
-    uint32_t item = 0, cc = 0, nch = 0, it_lane = 0, it_half = 0, it_bnd = 0;
+    uint32_t cc = 0, nch = 0, it_lane = 0, it_half = 0, it_bnd = 0, it_idx = 0;
     const uint8_t *it_db = nullptr;
+    int drained = 0;
 
-    for (;;) {
-        if (feeding && cc == nch) {                // wave-uniform: pull the next item
+    auto produce = [&](LaneFeed &f) -> bool {   // false: nothing left and the pipeline has drained
+        if (feeding && cc == nch) {
             uint32_t idx = 0;
             if (lane == 0) idx = atomicAdd(p.queue, 1u);
             idx = __builtin_amdgcn_readfirstlane(idx);
@@ -327,52 +340,65 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
                 feeding = false;
             } else {
                 const LaneItem iv = p.items[idx];
-                item = idx; cc = 0; nch = iv.ncols / C; it_db = iv.db; it_lane = iv.lane; it_half = iv.half; it_bnd = iv.bnd_off;
+                it_idx = idx; cc = 0; nch = iv.ncols / C; it_db = iv.db; it_lane = iv.lane; it_half = iv.half; it_bnd = iv.bnd_off;
             }
         }
-        uint32_t wa = 0x18181818u, wb = 0x18181818u;   // pad residues (code 24) while draining
-        uint2 b4[C];
 #pragma unroll
-        for (int jj = 0; jj < C; ++jj) b4[jj] = make_uint2(0u, 0u);
+        for (int jj = 0; jj < C; ++jj) { f.b[jj] = make_uint2(0u, 0u); f.flags[jj] = 0; }
+        f.wa = f.wb = 0x18181818u;   // pad residues (code 24) while draining
+        f.item = it_idx; f.col0 = 0; f.half = it_half;
         if (feeding) {
-            const uint2 w = *(const uint2 *)(it_db + ((size_t)cc * 64 + it_lane) * 8);   // uniform address
-            wa = PK ? w.x : (it_half ? w.y : w.x);
-            wb = w.y;
+            // uniform address; the value is NOT looked at here, so the load stays in flight while the
+            // previous chunk is computed
+            const unsigned long long w = *(const __attribute__((address_space(1))) unsigned long long *)(uintptr_t)(it_db + ((size_t)cc * 64 + it_lane) * 8);
+            f.wa = (uint32_t)w;
+            f.wb = (uint32_t)(w >> 32);
+            f.col0 = it_bnd + cc * C;
             if (!p.first_pass) {
 #pragma unroll
-                for (int jj = 0; jj < C; ++jj) b4[jj] = p.bnd[(size_t)it_bnd + cc * C + jj];
+                for (int jj = 0; jj < C; ++jj) f.b[jj] = p.bnd[(size_t)f.col0 + jj];
             }
-        } else {
-            if (drained >= 64) break;             // every lane has seen the last real column
-            drained += C;
+#pragma unroll
+            for (int jj = 0; jj < C; ++jj) f.flags[jj] = kFlagReal;
+            if (cc == 0) f.flags[0] |= kFlagStart;
+            if (cc + 1 == nch) f.flags[C - 1] |= kFlagEnd;
+            ++cc;
+            return true;
         }
+        drained += C;
+        return drained <= 64 + 2 * C;   // the last real column needs 1 + 63 more steps to leave lane 63
+    };
+
+    LaneFeed nxt;
+    bool more = produce(nxt);
+    while (more) {
+        LaneFeed cur = nxt;
+        more = produce(nxt);         // loads of the next chunk are in flight while this one is computed
+        if (!PK && cur.half) cur.wa = cur.wb;
 #pragma unroll
         for (int jj = 0; jj < C; ++jj) {
-            uint32_t d0 = (wa >> (8 * jj)) & 0xffu;
-            if (PK) d0 |= ((wb >> (8 * jj)) & 0xffu) << 8;
-            if (feeding) d0 |= kFlagReal;
-            if (feeding && cc == 0 && jj == 0) d0 |= kFlagStart;
-            if (feeding && cc + 1 == nch && jj == C - 1) d0 |= kFlagEnd;
-            const uint32_t col0 = it_bnd + cc * C + jj;
-            // hand-over: every lane takes its left neighbour's column, lane 0 the next one
-            const uint32_t D = dpp_shr1(oD, d0);
-            const uint32_t Hin = dpp_shr1(oH, b4[jj].x), Fin = dpp_shr1(oF, b4[jj].y);
-            const uint32_t Tin = dpp_shr1(oT, 0u), Sin = dpp_shr1(oS, item), Cin = dpp_shr1(oC, col0);
+            uint32_t d0 = ((cur.wa >> (8 * jj)) & 0xffu) | cur.flags[jj];
+            if (PK) d0 |= ((cur.wb >> (8 * jj)) & 0xffu) << 8;
+            // residue stream, one step ahead: fetch the scores of the NEXT column now
+            const uint32_t Dn = dpp_shr1(oDn, d0);
+            const uint4 an = *(const uint4 *)(my_prof + (Dn & 0xffu) * PS);
+            uint4 bn = make_uint4(0, 0, 0, 0);
+            if (PK) bn = *(const uint4 *)(my_prof + ((Dn >> 8) & 0xffu) * PS);
+            // boundary stream: every lane takes its left neighbour's bottom row, lane 0 the stored top boundary
+            const uint32_t Hin = dpp_shr1(oH, pb.x), Fin = dpp_shr1(oF, pb.y);
+            const uint32_t Tin = dpp_shr1(oT, 0u), Sin = dpp_shr1(oS, pitem), Cin = dpp_shr1(oC, pcol);
+            const uint32_t D = Dcur;
             if (D & kFlagStart) {                 // first column of an alignment reaches this lane
 #pragma unroll
                 for (int r = 0; r < TR; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
                 best = Ops::zero(); diag = Ops::zero();
             }
-            const unsigned char *pa = my_prof + (D & 0xffu) * PS;
             V hd = diag;
             diag = Ops::from_bits(Hin);
             V F = Ops::from_bits(Fin);
-            const uint4 a = *(const uint4 *)pa;
-            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+            const uint32_t aw[4] = {acur.x, acur.y, acur.z, acur.w};
             if (PK) {
-                const unsigned char *pb = my_prof + ((D >> 8) & 0xffu) * PS;
-                const uint4 b = *(const uint4 *)pb;
-                const uint32_t bw[4] = {b.x, b.y, b.z, b.w};
+                const uint32_t bw[4] = {bcur.x, bcur.y, bcur.z, bcur.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     cell<Ops>(hd, H[2 * q], E[2 * q], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)), goe, ge);
@@ -385,7 +411,7 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
                     cell<Ops>(hd, H[2 * q + 1], E[2 * q + 1], F, best, Ops::from_bits((uint32_t)((int)aw[q] >> 16)), goe, ge);
                 }
             }
-            oH = Ops::bits(H[TR - 1]); oF = Ops::bits(F); oD = D; oS = Sin; oC = Cin; oT = Tin;
+            oH = Ops::bits(H[TR - 1]); oF = Ops::bits(F); oS = Sin; oC = Cin; oT = Tin;
             if (D & kFlagEnd) oT = Ops::bits(Ops::vmax(Ops::from_bits(Tin), best));   // running best of the alignment
             if (lane == last_lane && (D & kFlagReal)) {   // fill / drain columns must never reach memory
                 if (!p.last_pass) p.bnd[Cin] = make_uint2(oH, oF);
@@ -400,8 +426,10 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
                     }
                 }
             }
+            // advance both streams
+            oDn = Dn; Dcur = Dn; acur = an; bcur = bn;
+            pb = cur.b[jj]; pitem = cur.item; pcol = cur.col0 + jj;
         }
-        if (feeding) ++cc;
     }
 }
 
@@ -420,7 +448,7 @@ hipError_t launch_lane(Mode mode, int n_wg, const LaneParams &p, hipStream_t s)
 __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__restrict__ n,
                               const uint32_t *__restrict__ disp, uint32_t vl_groups, uint32_t vl,
                               const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols,
-                              uint8_t *__restrict__ tiled)
+                              uint8_t *__restrict__ tiled, uint32_t *__restrict__ seq_len)
 {
     const uint32_t g = blockIdx.x;
     const uint32_t nch = gcols[g] / kChunkCols;
@@ -432,7 +460,7 @@ __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__r
         for (int hh = 0; hh < 2; ++hh) {
             const uint32_t sl = l + 64 * hh;          // sequence within the device group
             const uint32_t v = g * per + sl / vl, kk = sl % vl;
-            uint32_t word = 0;
+            uint32_t word = 0, real_end = 0;
 #pragma unroll
             for (int jj = 0; jj < kChunkCols; ++jj) {
                 const uint32_t col = c * kChunkCols + jj;
@@ -441,51 +469,47 @@ __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__r
                     code = b[(size_t)disp[v] + (size_t)col * vl + kk];
                     if (code > 24) code = 24;         // out-of-alphabet bytes score like padding
                 }
+                if (code != 24) real_end = col + 1;
                 word |= code << (8 * jj);
             }
             w[hh] = word;
+            // true length of every sequence = 1 + its last non-padding column (the reference layout only
+            // carries group lengths); the lane-systolic kernel stops each alignment there
+            if (real_end) atomicMax(seq_len + (size_t)g * kGroupSeqs + sl, real_end);
         }
         *(uint2 *)(tiled + goff[g] + (size_t)idx * 8) = make_uint2(w[0], w[1]);
     }
 }
 
 hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t vl_groups, uint32_t vl,
-                         const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled, hipStream_t s)
+                         const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled, uint32_t *seq_len,
+                         hipStream_t s)
 {
     if (dev_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(retile_kernel, dim3(dev_groups), dim3(256), 0, s, b, n, disp, vl_groups, vl, goff, gcols, tiled);
+    hipLaunchKernelGGL(retile_kernel, dim3(dev_groups), dim3(256), 0, s, b, n, disp, vl_groups, vl, goff, gcols, tiled, seq_len);
     return hipGetLastError();
 }
 
 // ---- saturation bookkeeping ----------------------------------------------------------------
-__global__ void flag_saturated_kernel(const int32_t *__restrict__ scores, uint64_t n, uint8_t *__restrict__ flags)
+// list[i] = slots whose packed-int16 best saturated (== 32767, CPUsearch.c:820-824 "overflow detection");
+// their scores are zeroed so that the int32 re-run can atomicMax its result in.  *count may exceed cap:
+// the host then re-runs with a larger list.
+__global__ void collect_saturated_kernel(int32_t *__restrict__ scores, uint64_t n, uint32_t *__restrict__ list,
+                                         uint32_t *__restrict__ count, uint32_t cap)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool sat = i < n && scores[i] >= 32767;
-    const unsigned long long m = __ballot(sat);
-    if ((threadIdx.x & 63) == 0 && i < n) flags[i >> 6] = m ? 1 : 0;
+    if (i < n && scores[i] >= 32767) {
+        const uint32_t k = atomicAdd(count, 1u);
+        if (k < cap) { list[k] = (uint32_t)i; scores[i] = 0; }
+    }
 }
 
-hipError_t launch_flag_saturated(const int32_t *scores, uint64_t n, uint8_t *flags, hipStream_t s)
+hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(flag_saturated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, n, flags);
+    hipLaunchKernelGGL(collect_saturated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, n, list, count, cap);
     return hipGetLastError();
 }
-
-__global__ void reset_halves_kernel(int32_t *scores, const uint32_t *half_slots, uint32_t count)
-{
-    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i < count) scores[(size_t)half_slots[i] * 64 + (threadIdx.x & 63)] = 0;
-}
-
-hipError_t launch_reset_halves(int32_t *scores, const uint32_t *half_slots, uint32_t count, hipStream_t s)
-{
-    if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(reset_halves_kernel, dim3((count + 3) / 4), dim3(256), 0, s, scores, half_slots, count);
-    return hipGetLastError();
-}
-
 
 // ---- device top-r candidates ------------------------------------------------------------------
 // Replaces sort_scores + the print loop's first r rows (utils.c:71-86, swimm.c:151-160) for r <= 64:

@@ -101,6 +101,8 @@ struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; };
 struct swimm_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // lane-systolic tail runs beside the bulk kernel
+    hipEvent_t ev_ready = nullptr, ev_tail = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cu = 0;
     // options
@@ -117,6 +119,7 @@ struct swimm_hip_ctx {
     std::vector<ChunkRec> chunks;
     std::vector<GroupDesc> groups;
     std::vector<uint64_t> group_col_off;
+    std::vector<uint32_t> seq_len;      // true length of every local slot (from the re-tile kernel)
     uint64_t total_cols = 0;
     DevBuf<GroupDesc> d_groups;
     bool groups_dirty = true;
@@ -125,12 +128,12 @@ struct swimm_hip_ctx {
     DevBuf<int32_t> d_scores;
     DevBuf<int16_t> d_prof;
     DevBuf<uint2> d_bnd;
-    DevBuf<uint8_t> d_flags;
-    DevBuf<uint32_t> d_slots;
     DevBuf<int64_t> d_gbase;
     DevBuf<uint32_t> d_gvalid;
     DevBuf<unsigned long long> d_keys;
     DevBuf<uint32_t> d_queue;
+    DevBuf<uint2> d_bnd2;               // pass boundary of the lane kernel (its own stream)
+    DevBuf<uint32_t> d_satlist;
     // stats of the last search
     double kernel_ms = 0;
     uint64_t cells = 0, promoted = 0;
@@ -278,8 +281,12 @@ int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, DbPlan **out)
             const GroupDesc &gd = c->groups[g];
             if (!is_tail[g]) { units.push_back(WorkUnit{g, 0, 0, gd.ncols, c->group_col_off[g]}); continue; }
             for (uint32_t l = 0; l < 64; ++l) {
+                // a pair only runs to the end of its longer member, not to the end of the group
+                const uint32_t len = std::max(c->seq_len[gd.seq0 + l], c->seq_len[gd.seq0 + 64 + l]);
+                if (len == 0) continue;                 // empty pair: scores stay 0
                 LaneItem li{};
-                li.db = gd.db; li.lane = l; li.half = 0; li.ncols = gd.ncols; li.slot_a = gd.seq0 + l; li.slot_b = gd.seq0 + 64 + l;
+                li.db = gd.db; li.lane = l; li.half = 0; li.ncols = (len + kChunkCols - 1) / kChunkCols * kChunkCols;
+                li.slot_a = gd.seq0 + l; li.slot_b = gd.seq0 + 64 + l;
                 tail.push_back(li);
             }
         }
@@ -333,12 +340,12 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
 }
 
 // all passes of the lane-systolic kernel over one work list for one query
-int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row)
+int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row, hipStream_t st)
 {
     if (ll.n == 0) return 0;
     const int rows_pass = 64 * kLaneRows;
     const int passes = (m + rows_pass - 1) / rows_pass;
-    if (passes > 1) HIP_TRY(c->d_bnd.reserve(std::max<uint64_t>(ll.cols, 1)));
+    if (passes > 1) HIP_TRY(c->d_bnd2.reserve(std::max<uint64_t>(ll.cols, 1)));
     HIP_TRY(c->d_queue.reserve(1));
     // 4 waves per workgroup; enough workgroups to fill the chip (58 VGPRs: 8 waves/SIMD, 26 KB LDS: 6 per CU)
     const int n_wg = (int)std::max<uint64_t>(1, std::min<uint64_t>((ll.n + 3) / 4, (uint64_t)c->num_cu * 6));
@@ -351,14 +358,14 @@ int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, con
         p.prof_stride = qp.mpad;
         p.r0 = (uint32_t)(pass * rows_pass);
         p.rows = (uint32_t)std::min(rows_pass, m - pass * rows_pass);
-        p.bnd = c->d_bnd.p;
+        p.bnd = c->d_bnd2.p;
         p.first_pass = pass == 0;
         p.last_pass = pass == passes - 1;
         p.out = out_row;
         p.goe = c->open_gap + c->extend_gap;
         p.ge = c->extend_gap;
-        HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, sizeof(uint32_t), c->stream));
-        HIP_TRY(launch_lane(mode, n_wg, p, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, sizeof(uint32_t), st));
+        HIP_TRY(launch_lane(mode, n_wg, p, st));
         c->launches++;
         c->cells += ll.cell_cols * (uint64_t)rows_pass * (mode == Mode::PK16 ? 2 : 1);
     }
@@ -414,50 +421,71 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     HIP_TRY(hipMemsetAsync(c->d_scores.p, 0, (size_t)qn * S * sizeof(int32_t), c->stream));
 
     const Mode main_mode = c->opt_force_i32 ? Mode::I32 : Mode::PK16;
+    // buffers that later launches grow are sized up front: a reallocation in the middle of the
+    // two-stream phase would free memory a kernel in flight still uses
+    {
+        uint64_t need_bnd = 0, need_bnd2 = 0;
+        for (uint32_t q = 0; q < qn; ++q) {
+            int per_cu = 1;
+            if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
+            DbPlan *dp = nullptr;
+            if (get_db_plan(c, main_mode, c->num_cu * per_cu, &dp)) return 1;
+            if (qps[q].passes > 1 && dp->have_main) need_bnd = std::max<uint64_t>(need_bnd, dp->main.bnd_cols * 64);
+            if (c->qm[q] > 64 * kLaneRows) need_bnd2 = std::max<uint64_t>(need_bnd2, dp->tail.cols);
+        }
+        HIP_TRY(c->d_bnd.reserve(need_bnd));
+        HIP_TRY(c->d_bnd2.reserve(need_bnd2));
+        HIP_TRY(c->d_queue.reserve(1));
+    }
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
     for (uint32_t q = 0; q < qn; ++q) {
         int per_cu = 1;
         if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
         DbPlan *dp = nullptr;
         if (get_db_plan(c, main_mode, c->num_cu * per_cu, &dp)) return 1;
         int32_t *row = c->d_scores.p + (size_t)q * S;
-        // long-sequence tail first (few long chains), then the bulk
-        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row)) return 1;
+        // the long-sequence tail (a few long serial chains, one wave each) runs on its own stream beside the
+        // bulk kernel: 3 bulk waves (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly
+        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row, c->stream2)) return 1;
         if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row)) return 1;
     }
+    HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
     // promotion: sequences whose int16 best saturated are recomputed in int32 (CPUsearch.c:820-957), every
     // one of them as its own lane-systolic item
     if (main_mode == Mode::PK16) {
-        std::vector<uint8_t> flags(S / 64);
+        const uint32_t cap = 1u << 16;
+        std::vector<uint32_t> list;
         for (uint32_t q = 0; q < qn; ++q) {
             if ((long)c->qm[q] * c->max_pos < 32767) continue;   // cannot saturate
             int32_t *row = c->d_scores.p + (size_t)q * S;
-            HIP_TRY(c->d_flags.reserve(S / 64));
-            HIP_TRY(launch_flag_saturated(row, S, c->d_flags.p, c->stream));
-            HIP_TRY(hipMemcpyAsync(flags.data(), c->d_flags.p, S / 64, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c->d_satlist.reserve((size_t)cap + 1));
+            uint32_t *d_count = c->d_satlist.p + cap;
+            HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
+            HIP_TRY(launch_collect_saturated(row, S, c->d_satlist.p, d_count, cap, c->stream));
+            uint32_t count = 0;
+            HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            if (count == 0) continue;
+            if (count > cap) return fail("more than %u saturated alignments for query %u: use force_i32", cap, q);
+            list.resize(count);
+            HIP_TRY(hipMemcpy(list.data(), c->d_satlist.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
             std::vector<LaneItem> items;
-            std::vector<uint32_t> slots;
-            for (uint32_t g = 0; g < c->groups.size(); ++g)
-                for (uint32_t h = 0; h < 2; ++h) {
-                    const uint32_t slot = c->groups[g].seq0 / 64 + h;
-                    if (!flags[slot]) continue;
-                    slots.push_back(slot);
-                    for (uint32_t l = 0; l < 64; ++l) {
-                        LaneItem li{};
-                        li.db = c->groups[g].db; li.lane = l; li.half = h; li.ncols = c->groups[g].ncols;
-                        li.slot_a = slot * 64 + l; li.slot_b = 0;
-                        items.push_back(li);
-                    }
-                }
-            if (items.empty()) continue;
+            for (uint32_t slot : list) {
+                const uint32_t g = slot / kGroupSeqs, within = slot % kGroupSeqs;
+                LaneItem li{};
+                li.db = c->groups[g].db; li.lane = within % 64; li.half = within / 64;
+                li.ncols = (c->seq_len[slot] + kChunkCols - 1) / kChunkCols * kChunkCols;
+                li.slot_a = slot; li.slot_b = 0;
+                if (li.ncols) items.push_back(li);
+            }
             c->promoted += items.size();
-            HIP_TRY(c->d_slots.reserve(slots.size()));
-            HIP_TRY(hipMemcpyAsync(c->d_slots.p, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(launch_reset_halves(row, c->d_slots.p, (uint32_t)slots.size(), c->stream));
             LaneList ll;
             if (upload_lane_items(c, items, ll)) return 1;
-            const int rc = run_lane_passes(c, Mode::I32, qps[q], c->qm[q], ll, row);
+            HIP_TRY(c->d_bnd2.reserve(ll.cols));
+            const int rc = run_lane_passes(c, Mode::I32, qps[q], c->qm[q], ll, row, c->stream);
             if (rc == 0) HIP_TRY(hipStreamSynchronize(c->stream));
             ll.release();
             if (rc) return 1;
@@ -503,8 +531,10 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     swimm_hip_ctx *c = new swimm_hip_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess) {
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return fail("swimm_hip_create: stream/event creation failed");
     }
@@ -518,9 +548,12 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
     c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
-    c->d_flags.release(); c->d_slots.release(); c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_queue.release();
+    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_queue.release(); c->d_bnd2.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -577,9 +610,10 @@ int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint
     }
     uint8_t *d_b = nullptr, *d_tiled = nullptr;
     uint16_t *d_n = nullptr;
-    uint32_t *d_disp = nullptr, *d_gcols = nullptr;
+    uint32_t *d_disp = nullptr, *d_gcols = nullptr, *d_len = nullptr;
     uint64_t *d_goff = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_b); (void)hipFree(d_n); (void)hipFree(d_disp); (void)hipFree(d_gcols); (void)hipFree(d_goff); };
+    std::vector<uint32_t> lens((size_t)dev_groups * kGroupSeqs);
+    auto cleanup = [&]() { (void)hipFree(d_b); (void)hipFree(d_n); (void)hipFree(d_disp); (void)hipFree(d_gcols); (void)hipFree(d_goff); (void)hipFree(d_len); };
 #define TRY_OR_CLEAN(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); (void)hipFree(d_tiled); return fail("%s: %s", #expr, hipGetErrorString(e__)); } } while (0)
     TRY_OR_CLEAN(hipMalloc((void **)&d_b, vD));
     TRY_OR_CLEAN(hipMalloc((void **)&d_n, group_count * sizeof(uint16_t)));
@@ -587,12 +621,15 @@ int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint
     TRY_OR_CLEAN(hipMalloc((void **)&d_gcols, dev_groups * sizeof(uint32_t)));
     TRY_OR_CLEAN(hipMalloc((void **)&d_goff, dev_groups * sizeof(uint64_t)));
     TRY_OR_CLEAN(hipMalloc((void **)&d_tiled, bytes));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_len, lens.size() * sizeof(uint32_t)));
+    TRY_OR_CLEAN(hipMemsetAsync(d_len, 0, lens.size() * sizeof(uint32_t), c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(d_b, b, vD, hipMemcpyHostToDevice, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(d_n, n, group_count * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(d_disp, b_disp, group_count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(d_gcols, gcols.data(), dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(d_goff, goff.data(), dev_groups * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(launch_retile(d_b, d_n, d_disp, group_count, vl, d_goff, d_gcols, dev_groups, d_tiled, c->stream));
+    TRY_OR_CLEAN(launch_retile(d_b, d_n, d_disp, group_count, vl, d_goff, d_gcols, dev_groups, d_tiled, d_len, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(lens.data(), d_len, lens.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
 #undef TRY_OR_CLEAN
     cleanup();
@@ -611,6 +648,7 @@ int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint
         c->group_col_off.push_back(c->total_cols);
         c->total_cols += gcols[g];
     }
+    c->seq_len.insert(c->seq_len.end(), lens.begin(), lens.end());
     c->chunks.push_back(rec);
     c->groups_dirty = true;
     return 0;
@@ -621,7 +659,7 @@ int swimm_hip_clear_db(swimm_hip_ctx *c)
     if (!c) return fail("swimm_hip_clear_db: NULL ctx");
     (void)hipSetDevice(c->device);
     for (auto &ch : c->chunks) (void)hipFree(ch.d_tiled);
-    c->chunks.clear(); c->groups.clear(); c->group_col_off.clear();
+    c->chunks.clear(); c->groups.clear(); c->group_col_off.clear(); c->seq_len.clear();
     c->total_cols = 0;
     release_plans(c);
     c->groups_dirty = true;

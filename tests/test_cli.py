@@ -118,6 +118,6 @@ def test_search_mode1_gpu_listing(dbprefix, golden):
     q = os.path.join(GOLDEN, golden["query_fasta"])
     p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-x", "1", "-r", "30", "-k", "30000")
     check_listing(p.stdout, golden, dbprefix, "blosum62_g10_e2", 30)
-    assert "Execution mode:\t\t\tMI355X only (1 GPUs)\n" in p.stdout and "Promoted to int32:\t\t64 alignments\n" in p.stdout
+    assert "Execution mode:\t\t\tMI355X only (1 GPUs)\n" in p.stdout and "Promoted to int32:\t\t1 alignments\n" in p.stdout
     p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-r", "413", "-s", "blosum50")   # r > 64: host selection path
     check_listing(p.stdout, golden, dbprefix, "blosum50_g10_e2", 413)

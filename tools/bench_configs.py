@@ -66,8 +66,11 @@ def main():
     ap.add_argument("--max-waves", type=int, default=0)
     ap.add_argument("--wgs-per-cu", type=int, default=0)
     ap.add_argument("--per-query", action="store_true")
+    ap.add_argument("--only", type=str, default="", help="comma-separated indices into the config's query list")
     args = ap.parse_args()
-    cfg = CFG[args.config]
+    cfg = dict(CFG[args.config])
+    if args.only:
+        cfg["queries"] = [cfg["queries"][int(i)] for i in args.only.split(",")]
     t0 = time.time()
     L, codes, offs, a, m, disp = build(cfg, args.scale, {"c2": 2, "c3": 3, "c4": 5, "c5": 5}[args.config])
     chunks = host.Chunks(L, codes, 128, 96 << 20)

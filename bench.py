@@ -119,11 +119,26 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    share = os.environ.get("SWIMM_BENCH_SHARE_DEVICE") == "1"   # rehearsal only: every rank on GPU 0, gloo only
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
+    rccl = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # control plane (barrier, max-over-ranks) on gloo; the only data exchange of the path -- 20 (score, index)
+        # pairs per rank and step -- goes over RCCL
+        dist.init_process_group(backend="gloo")
+        if not share:
+            try:
+                rccl = dist.new_group(backend="nccl")
+                t = torch.ones(1, device="cuda")
+                dist.all_reduce(t, group=rccl)
+                torch.cuda.synchronize()
+                assert int(t.item()) == world
+            except Exception as e:   # result path only: fall back to gloo, say so in the output
+                print(f"[rank {rank}] RCCL group unavailable ({e}); top-r lists go over gloo", file=sys.stderr)
+                rccl = None
 
     sm = submat.table("blosum62")
     shard = build_shard(2 + 1000 * rank, args.scale)
@@ -132,7 +147,7 @@ def main():
     m = np.array([len(q)], dtype=np.uint16)
     disp = np.array([0, len(q)], dtype=np.uint32)
 
-    searcher = hip_backend.HipSearcher(local_rank)
+    searcher = hip_backend.HipSearcher(dev_index)
     if args.rows_per_wave:
         searcher.set_option("rows_per_wave", args.rows_per_wave)
     if args.max_waves:
@@ -147,16 +162,22 @@ def main():
     padded_bytes = chunks.vD
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier()
         torch.cuda.synchronize()
 
     def one_step():
         ts, ti, wt = searcher.search_topr(TOP_R, shard["n"])
         if dist is not None:   # result path only: 20 (score, index) pairs per rank
-            mine = torch.from_numpy(np.concatenate([ts[0].astype(np.int64), ti[0] + rank * (1 << 40)])).cuda()
-            allv = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allv, mine)
+            mine = torch.from_numpy(np.concatenate([ts[0].astype(np.int64), ti[0] + rank * (1 << 40)]))
+            if rccl is not None:
+                mine = mine.cuda()
+                allv = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(allv, mine, group=rccl)
+            else:
+                allv = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(allv, mine)
             g = torch.stack(allv).cpu().numpy()
             ms, mi = host.topr_merge(g[:, :TOP_R].astype(np.int32), g[:, TOP_R:], TOP_R)
             return ms, mi, wt
@@ -174,10 +195,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        res = torch.tensor([shard["residues"]], dtype=torch.float64, device="cuda")
+        res = torch.tensor([shard["residues"]], dtype=torch.float64)
         dist.all_reduce(res, op=dist.ReduceOp.SUM)
         total_residues = float(res.item())
     else:
@@ -213,7 +234,8 @@ def main():
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "c2: 375-aa query x 1M synthetic proteins per GPU, BLOSUM62 g10 e2, top-20",
                        "query_len": m_real, "db_sequences_per_gpu": shard["n"], "db_residues_per_gpu": shard["residues"],
-                       "parallelism": f"db-shard x{world}", "rows_per_wave": 32, "scale": args.scale},
+                       "parallelism": f"db-shard x{world}", "rows_per_wave": 32, "scale": args.scale,
+                       "topr_exchange": "none" if world == 1 else ("rccl all_gather" if rccl is not None else "gloo all_gather")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "sw_pipe_kernel<32,packed-int16>", "kernel_ms": round(k_ms / launches, 4),
@@ -240,7 +262,7 @@ def main():
     searcher.close()
     chunks.close()
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,0 +1,67 @@
+"""BASELINE.json's full-size headline workload (c2: 375-aa query x 1 000 004 synthetic proteins,
+6e8 residues) on the GPU, checked through size-independent properties plus a sampled comparison with
+the CPU oracle (a full oracle pass would take minutes on the test box):
+
+  * decomposition invariance -- the score vector does not depend on how the DP is cut into strips /
+    waves / passes / kernels (rows_per_wave 16 vs 32, single-wave workgroups, every group through the
+    lane-systolic kernel): four different schedules of the same recurrence must agree bit for bit on
+    all 1 000 004 scores;
+  * known answers -- the planted exact copy scores the query's self score, mutated copies score less,
+    in order of mutation rate;
+  * sampled oracle -- 400 randomly chosen sequences + the top-20 against sw_oracle_pair;
+  * top-r -- device top-20 == host selection over the full vector == reference order (score, index desc).
+"""
+import numpy as np
+import pytest
+
+import bench
+from oracle import port
+from swimm_amd import hip_backend, host, submat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2():
+    shard = bench.build_shard(2, 1.0)
+    chunks = host.Chunks(shard["lengths"], shard["codes"], 128, 96 << 20)
+    yield shard, chunks
+    chunks.close()
+
+
+def _search(shard, chunks, opts, topr=False):
+    q = shard["query"]
+    with hip_backend.HipSearcher(0) as s:
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.set_queries(q, np.array([len(q)], np.uint16), np.array([0, len(q)], np.uint32), submat.table("blosum62"), 10, 2)
+        for ch in chunks.chunks:
+            s.add_chunk(ch["b"], ch["n"], ch["disp"], 128, ch["first_group"])
+        full, _ = s.search(chunks.vc * 128)
+        top = s.search_topr(20, shard["n"]) if topr else None
+    return full[0, :shard["n"]].copy(), top
+
+
+def test_c2_full_size(c2):
+    shard, chunks = c2
+    assert shard["n"] == 1_000_004 and 5.9e8 < shard["residues"] < 6.1e8
+    base, top = _search(shard, chunks, {}, topr=True)
+    for opts in ({"rows_per_wave": 16}, {"max_waves": 1}, {"tail_mode": 1}):
+        other, _ = _search(shard, chunks, opts)
+        assert np.array_equal(base, other), opts
+    sm = submat.table("blosum62")
+    q = shard["query"]
+    self_score = port.pair_score(q, q, sm, 10, 2)
+    order = np.argsort(-base.astype(np.int64), kind="stable")
+    assert base[order[0]] == self_score                       # planted 0 % copy
+    assert base[order[0]] > base[order[1]] > base[order[2]] > base[order[3]] > base[order[4]]   # 10/30/50 % copies, then background
+    offs = np.concatenate([[0], np.cumsum(shard["lengths"].astype(np.int64))])
+    rng = np.random.default_rng(7)
+    picks = list(rng.integers(0, shard["n"], 400)) + [0, shard["n"] - 1] + list(order[:20])
+    for i in picks:
+        assert base[i] == port.pair_score(q, shard["codes"][offs[i]:offs[i + 1]], sm, 10, 2), i
+    ts, ti, _ = top
+    hs, hi = host.topr(base, 20)
+    assert np.array_equal(ts[0], hs) and np.array_equal(ti[0], hi)
+    os_, oi = port.topr(base, 20)
+    assert np.array_equal(hs, os_) and np.array_equal(hi, oi)

@@ -41,7 +41,7 @@ struct PipeParams {
     int goe, ge;                // open+extend, extend
 };
 
-enum class Mode { PK16, I32 };
+enum class Mode { PK16, I32, F16 };   // F16: packed binary16 first tier (pipeline kernel only)
 
 // ---- lane-systolic kernel: ONE wave aligns one packed pair (or one sequence in int32 mode) with its 64
 // lanes as the query strips; used for the long-sequence tail and for the int32 promotion re-runs, where
@@ -83,8 +83,8 @@ hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *di
                          const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled,
                          uint32_t *seq_len /* [dev_groups*128], zeroed; gets every sequence's true length */, hipStream_t s);
 
-// appends the slots whose int16 best saturated (>= 32767) to list (up to cap) and zeroes their scores
-hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s);
+// appends the slots whose score is >= thr (tier left its exact range) to list (up to cap) and zeroes them
+hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, int thr, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s);
 // per-block top-64 candidates of one query's score row: out_keys[block*64 + i] = ((score<<32 | global index) + 1),
 // 0 = empty; group_base[g] = global sorted index of the group's first sequence, group_valid[g] = real sequences in it
 hipError_t launch_topk64(const int32_t *scores, uint64_t n_slots, const int64_t *group_base, const uint32_t *group_valid,

@@ -63,6 +63,25 @@ struct OpsI32 {
     static __device__ __forceinline__ V subz(V a, V b) { int d = a - b; return d > 0 ? d : 0; }
 };
 
+// ---- cell arithmetic, packed 2 x f16: exact while every H <= 2047 (integers up to 2048 are exact in
+// binary16; a sum that would leave that range makes some H >= 2048, which the host detects on the final
+// score and re-runs in int16).  Buys v_pk_maximum3_f16 (gfx950): 8.5 instead of 10 VALU ops per 2 cells.
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+struct OpsF16 {
+    typedef v2h V;
+    static __device__ __forceinline__ V zero() { return (V)((_Float16)0.0f); }
+    static __device__ __forceinline__ V splat(int x) { return (V)((_Float16)(float)x); }
+    static __device__ __forceinline__ V from_bits(uint32_t x) { return __builtin_bit_cast(V, x); }
+    static __device__ __forceinline__ uint32_t bits(V x) { return __builtin_bit_cast(uint32_t, x); }
+    static __device__ __forceinline__ V vmax(V a, V b) { return __builtin_elementwise_max(a, b); }
+    static __device__ __forceinline__ V max3(V a, V b, V c)
+    {
+        V d;
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
+};
+
 template <class Ops>
 __device__ __forceinline__ void cell(typename Ops::V &hd, typename Ops::V &Hr, typename Ops::V &Er,
                                      typename Ops::V &F, typename Ops::V &best, typename Ops::V S,
@@ -82,6 +101,40 @@ __device__ __forceinline__ void cell(typename Ops::V &hd, typename Ops::V &Hr, t
     F = Ops::vmax(Ops::subz(F, ge), u);     // CPUsearch.c:629,632
 }
 
+// two consecutive query rows of one column.  goe / ge are the gap penalties in the form the tier wants
+// (f16: already negated).
+template <class Ops>
+__device__ __forceinline__ void cell2(typename Ops::V &hd, typename Ops::V &H0, typename Ops::V &E0, typename Ops::V &H1,
+                                      typename Ops::V &E1, typename Ops::V &F, typename Ops::V &best, typename Ops::V S0,
+                                      typename Ops::V S1, typename Ops::V goe, typename Ops::V ge)
+{
+    cell<Ops>(hd, H0, E0, F, best, S0, goe, ge);
+    cell<Ops>(hd, H1, E1, F, best, S1, goe, ge);
+}
+
+template <>
+__device__ __forceinline__ void cell2<OpsF16>(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2h &E1, v2h &F, v2h &best, v2h S0, v2h S1,
+                                              v2h ngoe, v2h nge)
+{
+    const v2h z = OpsF16::zero();
+    v2h t0 = hd + S0;                         // Hdiag + S
+    hd = H0;
+    v2h h0 = OpsF16::max3(t0, E0, F);         // E, F >= 0, so this is max(0, ...) too
+    H0 = h0;
+    v2h u0 = h0 + ngoe;                       // H - (open+extend)
+    E0 = OpsF16::max3(E0 + nge, u0, z);
+    F = OpsF16::max3(F + nge, u0, z);
+    v2h t1 = hd + S1;
+    hd = H1;
+    v2h h1 = OpsF16::max3(t1, E1, F);
+    H1 = h1;
+    v2h u1 = h1 + ngoe;
+    E1 = OpsF16::max3(E1 + nge, u1, z);
+    F = OpsF16::max3(F + nge, u1, z);
+    best = OpsF16::max3(best, h0, h1);        // one instruction for two rows
+    asm("" : "+v"(best));
+}
+
 __host__ __device__ constexpr size_t round16(size_t x) { return (x + 15) & ~(size_t)15; }
 // +16: the 25 code rows start 16 bytes (mod 256) apart, so codes d and d' share LDS banks for
 // ds_read_b128 only when d == d' (mod 16)
@@ -92,10 +145,12 @@ size_t pipe_lds_bytes(int T, int W)
     return round16((size_t)kCodes * prof_row_bytes(T * W)) + (size_t)W * 2 * kChunkCols * 64 * sizeof(uint2);
 }
 
-template <int T, bool PK>
+// M: 0 = packed int16, 1 = int32 (one sequence per lane), 2 = packed f16
+template <int T, int M>
 __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
 {
-    typedef typename std::conditional<PK, OpsPK, OpsI32>::type Ops;
+    constexpr bool PK = M != 1;
+    typedef typename std::conditional<M == 0, OpsPK, typename std::conditional<M == 1, OpsI32, OpsF16>::type>::type Ops;
     typedef typename Ops::V V;
     constexpr int C = kChunkCols;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -114,12 +169,17 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
         for (int idx = threadIdx.x; idx < kCodes * dw_per_code; idx += blockDim.x) {
             const int d = idx / dw_per_code, x = idx - d * dw_per_code;
             const uint32_t *src = (const uint32_t *)(p.prof + (size_t)d * p.prof_stride + p.r0);
-            *(uint32_t *)(prof_lds + d * PS + x * 4) = src[x];
+            uint32_t v = src[x];
+            if (M == 2) {                           // int16 scores -> binary16
+                const v2s sv = as_v2s(v);
+                v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)sv.x, (_Float16)(float)sv.y});
+            }
+            *(uint32_t *)(prof_lds + d * PS + x * 4) = v;
         }
     }
     __syncthreads();
 
-    const V goe = Ops::splat(p.goe), ge = Ops::splat(p.ge);
+    const V goe = Ops::splat(M == 2 ? -p.goe : p.goe), ge = Ops::splat(M == 2 ? -p.ge : p.ge);
     const uint32_t it_end = p.wg_first[blockIdx.x + 1];
     uint32_t it = p.wg_first[blockIdx.x];
     const int total = (int)p.wg_chunks[blockIdx.x];
@@ -192,15 +252,16 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
                         for (int q = 0; q < 4; ++q) {
                             // (A_r, B_r) pairs: low / high int16 of the two lookups
                             const int r = r8 * 8 + q * 2;
-                            cell<Ops>(hd, H[r], E[r], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)), goe, ge);
-                            cell<Ops>(hd, H[r + 1], E[r + 1], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
+                            cell2<Ops>(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
+                                       Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
+                                       Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
                         }
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int r = r8 * 8 + q * 2;
-                            cell<Ops>(hd, H[r], E[r], F, best, Ops::from_bits((uint32_t)(int)(short)(aw[q] & 0xffffu)), goe, ge);
-                            cell<Ops>(hd, H[r + 1], E[r + 1], F, best, Ops::from_bits((uint32_t)((int)aw[q] >> 16)), goe, ge);
+                            cell2<Ops>(hd, H[r], E[r], H[r + 1], E[r + 1], F, best, Ops::from_bits((uint32_t)(int)(short)(aw[q] & 0xffffu)),
+                                       Ops::from_bits((uint32_t)((int)aw[q] >> 16)), goe, ge);
                         }
                     }
                 }
@@ -213,7 +274,11 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (++cc == nch) {   // item finished: every strip contributes its best (CPUsearch.c:670-676)
-                if (PK) {
+                if (M == 2) {
+                    const v2h b2 = __builtin_bit_cast(v2h, Ops::bits(best));
+                    atomicMax(p.out + seq0 + lane, (int)(float)b2.x);
+                    atomicMax(p.out + seq0 + 64 + lane, (int)(float)b2.y);
+                } else if (PK) {
                     const v2s b2 = __builtin_bit_cast(v2s, Ops::bits(best));
                     atomicMax(p.out + seq0 + lane, (int)b2.x);
                     atomicMax(p.out + seq0 + 64 + lane, (int)b2.y);
@@ -228,32 +293,48 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
     }
 }
 
-template <int T, bool PK>
+template <int T, int M>
 static hipError_t launch_one(int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
     const size_t lds = pipe_lds_bytes(T, W);
-    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sw_pipe_kernel<T, PK>), dim3(n_wg), dim3(W * 64), lds, s, p);
+    hipLaunchKernelGGL((sw_pipe_kernel<T, M>), dim3(n_wg), dim3(W * 64), lds, s, p);
     return hipGetLastError();
+}
+
+template <int T>
+static hipError_t launch_mode(Mode mode, int W, int n_wg, const PipeParams &p, hipStream_t s)
+{
+    if (mode == Mode::PK16) return launch_one<T, 0>(W, n_wg, p, s);
+    if (mode == Mode::I32) return launch_one<T, 1>(W, n_wg, p, s);
+    return launch_one<T, 2>(W, n_wg, p, s);
 }
 
 hipError_t launch_pipe(Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
     if (W < 1 || W > kMaxWaves || n_wg < 1) return hipErrorInvalidValue;
-    const bool pk = mode == Mode::PK16;
-    if (T == 32) return pk ? launch_one<32, true>(W, n_wg, p, s) : launch_one<32, false>(W, n_wg, p, s);
-    if (T == 16) return pk ? launch_one<16, true>(W, n_wg, p, s) : launch_one<16, false>(W, n_wg, p, s);
+    if (T == 32) return launch_mode<32>(mode, W, n_wg, p, s);
+    if (T == 24) return launch_mode<24>(mode, W, n_wg, p, s);
+    if (T == 16) return launch_mode<16>(mode, W, n_wg, p, s);
     return hipErrorInvalidValue;
+}
+
+template <int T>
+static const void *kernel_ptr(Mode mode)
+{
+    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0>;
+    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1>;
+    return (const void *)sw_pipe_kernel<T, 2>;
 }
 
 hipError_t pipe_kernel_attributes(Mode mode, int T, int *num_regs)
 {
     hipFuncAttributes a;
     const void *f = nullptr;
-    const bool pk = mode == Mode::PK16;
-    if (T == 32) f = pk ? (const void *)sw_pipe_kernel<32, true> : (const void *)sw_pipe_kernel<32, false>;
-    else if (T == 16) f = pk ? (const void *)sw_pipe_kernel<16, true> : (const void *)sw_pipe_kernel<16, false>;
+    if (T == 32) f = kernel_ptr<32>(mode);
+    else if (T == 24) f = kernel_ptr<24>(mode);
+    else if (T == 16) f = kernel_ptr<16>(mode);
     else return hipErrorInvalidValue;
     hipError_t e = hipFuncGetAttributes(&a, f);
     if (e == hipSuccess) *num_regs = a.numRegs;
@@ -491,23 +572,24 @@ hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *di
 }
 
 // ---- saturation bookkeeping ----------------------------------------------------------------
-// list[i] = slots whose packed-int16 best saturated (== 32767, CPUsearch.c:820-824 "overflow detection");
+// list[i] = slots whose first-tier best left the tier's exact range (>= thr: 32767 for int16, CPUsearch.c:820-824
+// "overflow detection"; 2048 for f16);
 // their scores are zeroed so that the int32 re-run can atomicMax its result in.  *count may exceed cap:
 // the host then re-runs with a larger list.
-__global__ void collect_saturated_kernel(int32_t *__restrict__ scores, uint64_t n, uint32_t *__restrict__ list,
+__global__ void collect_saturated_kernel(int32_t *__restrict__ scores, uint64_t n, int thr, uint32_t *__restrict__ list,
                                          uint32_t *__restrict__ count, uint32_t cap)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && scores[i] >= 32767) {
+    if (i < n && scores[i] >= thr) {
         const uint32_t k = atomicAdd(count, 1u);
         if (k < cap) { list[k] = (uint32_t)i; scores[i] = 0; }
     }
 }
 
-hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s)
+hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, int thr, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(collect_saturated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, n, list, count, cap);
+    hipLaunchKernelGGL(collect_saturated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, n, thr, list, count, cap);
     return hipGetLastError();
 }
 

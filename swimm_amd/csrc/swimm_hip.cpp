@@ -108,6 +108,7 @@ struct swimm_hip_ctx {
     // options
     int opt_T = 32, opt_maxW = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
+    int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
     // queries (host copies; profiles are built per search because T/W may change)
     std::vector<int8_t> qcodes;
     std::vector<uint16_t> qm;
@@ -136,7 +137,7 @@ struct swimm_hip_ctx {
     DevBuf<uint32_t> d_satlist;
     // stats of the last search
     double kernel_ms = 0;
-    uint64_t cells = 0, promoted = 0;
+    uint64_t cells = 0, promoted = 0, promoted16 = 0;
     uint32_t launches = 0;
 };
 
@@ -158,8 +159,8 @@ int regs_to_waves_per_simd(int regs)
 QueryPlan choose_plan(const swimm_hip_ctx *c, int m)
 {
     QueryPlan q{};
-    q.T = (c->opt_T == 16) ? 16 : 32;
-    int maxW = (q.T == 32) ? 12 : 16;       // __launch_bounds__ of the two instantiations
+    q.T = (c->opt_T == 16 || c->opt_T == 24) ? c->opt_T : 32;
+    int maxW = (q.T == 32) ? 12 : 16;       // __launch_bounds__ of the instantiations
     if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
     const int strips = std::max(1, (m + q.T - 1) / q.T);
     q.passes = (strips + maxW - 1) / maxW;
@@ -269,13 +270,13 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, int n_wg)
 
 int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, DbPlan **out)
 {
-    const int key = n_wg | (mode == Mode::I32 ? (1 << 30) : 0);
+    const int key = n_wg | (mode == Mode::I32 ? (1 << 30) : 0);   // packed int16 and f16 share plans
     auto it = c->plans.find(key);
     if (it != c->plans.end()) { *out = &it->second; return 0; }
     std::vector<WorkUnit> units;
     std::vector<LaneItem> tail;
     uint64_t bnd_cols = 0;
-    if (mode == Mode::PK16) {
+    if (mode != Mode::I32) {
         const std::vector<uint8_t> is_tail = pick_tail(c, n_wg);
         for (uint32_t g = 0; g < c->groups.size(); ++g) {
             const GroupDesc &gd = c->groups[g];
@@ -334,7 +335,7 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
         p.out = out_row;
         HIP_TRY(launch_pipe(mode, qp.T, qp.W, pl.n_wg, p, c->stream));
         c->launches++;
-        c->cells += pl.total_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * (mode == Mode::PK16 ? 128 : 64);
+        c->cells += pl.total_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * (mode == Mode::I32 ? 64 : 128);
     }
     return 0;
 }
@@ -393,7 +394,7 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     const uint32_t qn = (uint32_t)c->qm.size();
     const uint64_t S = (uint64_t)c->groups.size() * kGroupSeqs;
     *slots_out = S;
-    c->kernel_ms = 0; c->cells = 0; c->promoted = 0; c->launches = 0;
+    c->kernel_ms = 0; c->cells = 0; c->promoted = 0; c->promoted16 = 0; c->launches = 0;
 
     // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
@@ -420,7 +421,7 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
     HIP_TRY(hipMemsetAsync(c->d_scores.p, 0, (size_t)qn * S * sizeof(int32_t), c->stream));
 
-    const Mode main_mode = c->opt_force_i32 ? Mode::I32 : Mode::PK16;
+    const Mode main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 ? Mode::F16 : Mode::PK16);
     // buffers that later launches grow are sized up front: a reallocation in the middle of the
     // two-stream phase would free memory a kernel in flight still uses
     {
@@ -453,25 +454,60 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     }
     HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
-    // promotion: sequences whose int16 best saturated are recomputed in int32 (CPUsearch.c:820-957), every
-    // one of them as its own lane-systolic item
-    if (main_mode == Mode::PK16) {
+    // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
+    // f16 results >= 2048 are re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; each
+    // re-run is a lane-systolic item (one wave per alignment)
+    if (main_mode != Mode::I32) {
         const uint32_t cap = 1u << 16;
         std::vector<uint32_t> list;
-        for (uint32_t q = 0; q < qn; ++q) {
-            if ((long)c->qm[q] * c->max_pos < 32767) continue;   // cannot saturate
+        auto collect = [&](uint32_t q, int thr, std::vector<uint32_t> &out) -> int {
             int32_t *row = c->d_scores.p + (size_t)q * S;
             HIP_TRY(c->d_satlist.reserve((size_t)cap + 1));
             uint32_t *d_count = c->d_satlist.p + cap;
             HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
-            HIP_TRY(launch_collect_saturated(row, S, c->d_satlist.p, d_count, cap, c->stream));
+            HIP_TRY(launch_collect_saturated(row, S, thr, c->d_satlist.p, d_count, cap, c->stream));
             uint32_t count = 0;
             HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (count == 0) continue;
-            if (count > cap) return fail("more than %u saturated alignments for query %u: use force_i32", cap, q);
-            list.resize(count);
-            HIP_TRY(hipMemcpy(list.data(), c->d_satlist.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (count > cap) return fail("more than %u alignments of query %u left the %s range: use force_i32", cap, q, thr == 2048 ? "f16" : "int16");
+            out.resize(count);
+            if (count) HIP_TRY(hipMemcpy(out.data(), c->d_satlist.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            return 0;
+        };
+        auto rerun = [&](uint32_t q, Mode mode, std::vector<LaneItem> &items) -> int {
+            if (items.empty()) return 0;
+            LaneList ll;
+            if (upload_lane_items(c, items, ll)) return 1;
+            HIP_TRY(c->d_bnd2.reserve(ll.cols));
+            const int rc = run_lane_passes(c, mode, qps[q], c->qm[q], ll, c->d_scores.p + (size_t)q * S, c->stream);
+            if (rc == 0) HIP_TRY(hipStreamSynchronize(c->stream));
+            ll.release();
+            return rc;
+        };
+        for (uint32_t q = 0; q < qn; ++q) {
+            const long bound = (long)c->qm[q] * c->max_pos;     // no alignment of this query can score more
+            if (main_mode == Mode::F16 && bound >= 2048) {
+                if (collect(q, 2048, list)) return 1;
+                std::vector<LaneItem> items;
+                std::vector<uint8_t> seen;
+                for (uint32_t slot : list) {                      // re-run the packed PAIR the slot belongs to
+                    const uint32_t g = slot / kGroupSeqs, l = slot % 64;
+                    const uint32_t pair = g * 64 + l;
+                    if (seen.size() <= pair) seen.resize(pair + 1, 0);
+                    if (seen[pair]) continue;
+                    seen[pair] = 1;
+                    const GroupDesc &gd = c->groups[g];
+                    const uint32_t len = std::max(c->seq_len[gd.seq0 + l], c->seq_len[gd.seq0 + 64 + l]);
+                    LaneItem li{};
+                    li.db = gd.db; li.lane = l; li.half = 0; li.ncols = (len + kChunkCols - 1) / kChunkCols * kChunkCols;
+                    li.slot_a = gd.seq0 + l; li.slot_b = gd.seq0 + 64 + l;
+                    if (li.ncols) items.push_back(li);
+                }
+                c->promoted16 += list.size();
+                if (rerun(q, Mode::PK16, items)) return 1;
+            }
+            if (bound < 32767) continue;                         // cannot saturate int16
+            if (collect(q, 32767, list)) return 1;
             std::vector<LaneItem> items;
             for (uint32_t slot : list) {
                 const uint32_t g = slot / kGroupSeqs, within = slot % kGroupSeqs;
@@ -482,13 +518,7 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
                 if (li.ncols) items.push_back(li);
             }
             c->promoted += items.size();
-            LaneList ll;
-            if (upload_lane_items(c, items, ll)) return 1;
-            HIP_TRY(c->d_bnd2.reserve(ll.cols));
-            const int rc = run_lane_passes(c, Mode::I32, qps[q], c->qm[q], ll, row, c->stream);
-            if (rc == 0) HIP_TRY(hipStreamSynchronize(c->stream));
-            ll.release();
-            if (rc) return 1;
+            if (rerun(q, Mode::I32, items)) return 1;
         }
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -775,13 +805,15 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail("swimm_hip_set_option: NULL argument");
     if (!strcmp(key, "rows_per_wave")) {
-        if (value != 16 && value != 32) return fail("rows_per_wave must be 16 or 32");
+        if (value != 16 && value != 24 && value != 32) return fail("rows_per_wave must be 16, 24 or 32");
         c->opt_T = value;
     } else if (!strcmp(key, "max_waves")) {
         if (value < 0 || value > kMaxWaves) return fail("max_waves must be 0..%d", kMaxWaves);
         c->opt_maxW = value;
     } else if (!strcmp(key, "force_i32")) {
         c->opt_force_i32 = value != 0;
+    } else if (!strcmp(key, "f16")) {
+        c->opt_f16 = value != 0;
     } else if (!strcmp(key, "tail_mode")) {
         if (value < 0 || value > 2) return fail("tail_mode must be 0 (auto), 1 (all groups via the lane kernel) or 2 (none)");
         c->opt_tail_mode = value;

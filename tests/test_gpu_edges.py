@@ -1,0 +1,93 @@
+"""Edge cases of the search path on the GPU vs the CPU oracle: degenerate sizes, gap extremes, ragged
+groups, the 16-bit length limits, and scores sitting exactly on the promotion thresholds
+(2047/2048: binary16 tier, 32766/32767/32768: int16 tier)."""
+import numpy as np
+import pytest
+
+from oracle import port
+from swimm_amd import hip_backend, host, submat
+
+pytestmark = pytest.mark.gpu
+
+CODE = {c: i for i, c in enumerate("ABCDEFGHIKLMNPQRSTVWXYZ")}
+
+
+def enc(s):
+    return np.array([CODE[c] for c in s], dtype=np.int8)
+
+
+def run_case(seqs, queries, matrix="blosum62", go=10, ge=2, opts=None, vl=128, max_chunk=1 << 20):
+    seqs = sorted(seqs, key=len)                       # the database must be length-sorted (stable)
+    lens = np.array([len(s) for s in seqs], dtype=np.uint16)
+    codes = np.concatenate([s for s in seqs] + [np.zeros(0, np.int8)]).astype(np.int8)
+    queries = sorted(queries, key=len)
+    m = np.array([len(q) for q in queries], dtype=np.uint16)
+    disp = np.concatenate([[0], np.cumsum(m)]).astype(np.uint32)
+    a = np.concatenate(queries).astype(np.int8)
+    sm = submat.table(matrix)
+    ch = host.Chunks(lens, codes, vl, max_chunk)
+    with hip_backend.HipSearcher(0) as s:
+        for k, v in (opts or {}).items():
+            s.set_option(k, v)
+        s.set_queries(a, m, disp, sm, go, ge)
+        for c in ch.chunks:
+            s.add_chunk(c["b"], c["n"], c["disp"], vl, c["first_group"])
+        got, _ = s.search(ch.vc * vl)
+        stats = s.last_stats()
+    ch.close()
+    want = np.array([[port.pair_score(q, d, sm, go, ge) if len(d) else 0 for d in seqs] for q in queries], dtype=np.int32)
+    assert np.array_equal(got[:, :len(seqs)], want), (got[:, :len(seqs)], want)
+    return want, stats
+
+
+def rnd(rng, n):
+    return rng.integers(0, 23, n).astype(np.int8)
+
+
+def test_degenerate_sizes():
+    rng = np.random.default_rng(3)
+    run_case([enc("W")], [enc("W")])                                   # 1 x 1
+    run_case([enc("A"), enc("WW"), enc("")], [enc("W"), enc("AW")])    # empty record, length-1 and -2 queries
+    run_case([rnd(rng, 5) for _ in range(129)], [rnd(rng, 33)])        # 128 + 1 sequences: second group almost empty
+    run_case([rnd(rng, int(n)) for n in rng.integers(1, 40, 300)], [rnd(rng, 1), rnd(rng, 7), rnd(rng, 64)], vl=16, max_chunk=600)
+
+
+@pytest.mark.parametrize("go,ge", [(0, 0), (0, 1), (1, 0), (127, 0), (100, 27), (5, 1)])
+def test_gap_extremes(go, ge):
+    rng = np.random.default_rng(go * 131 + ge)
+    base = rnd(rng, 200)
+    seqs = [rnd(rng, int(n)) for n in rng.integers(20, 400, 200)]
+    seqs += [np.concatenate([base[:90], rnd(rng, 7), base[90:]]), np.delete(base, slice(50, 58))]   # homologs with one gap
+    run_case(seqs, [base, base[:31]], go=go, ge=ge)
+    run_case(seqs, [base], go=go, ge=ge, opts={"tail_mode": 1})
+
+
+def test_length_limits():
+    rng = np.random.default_rng(9)
+    long_db = rnd(rng, 65535)                                           # longest sequence the .seq format can hold... minus rounding
+    seqs = [rnd(rng, 50), rnd(rng, 51), long_db[:65530]]
+    run_case(seqs, [long_db[1000:1030], rnd(rng, 5)])
+    long_q = rnd(rng, 20001)                                            # 53 passes of the workgroup pipeline, 40 of the lane kernel
+    seqs = [rnd(rng, int(n)) for n in rng.integers(1, 300, 140)] + [long_q[5000:5600].copy()]
+    run_case(seqs, [long_q])
+    run_case(seqs, [long_q], opts={"tail_mode": 2, "rows_per_wave": 16})
+
+
+@pytest.mark.parametrize("opts", [{}, {"f16": 0}, {"tail_mode": 2}, {"tail_mode": 1}])
+def test_scores_on_the_promotion_thresholds(opts):
+    """self scores of W^k + filler under BLOSUM62 (W 11, C 9, H 8, A 4, K 5): exactly 2046..2049 and 32766..32768"""
+    def mk(total):
+        k, rest = divmod(total, 11)
+        filler = {0: "", 1: None, 2: None, 3: None, 4: "A", 5: "K", 6: None, 7: "P", 8: "H", 9: "C", 10: "KK"}[rest]
+        if filler is None:                     # trade one W (11) for letters that reach the remainder + 11
+            k -= 1
+            filler = {12: "AH", 13: "AC", 14: "PP", 17: "CH"}[rest + 11]
+        return enc("W" * k + filler)
+    targets = [2046, 2047, 2048, 2049, 32766, 32767, 32768]
+    seqs = [mk(t) for t in targets]
+    rng = np.random.default_rng(5)
+    seqs += [rnd(rng, int(n)) for n in rng.integers(10, 200, 150)]
+    want, stats = run_case(seqs, [mk(t) for t in targets], opts=opts)
+    for t in targets:
+        assert (want == t).any(), t            # every threshold value really occurs
+    assert stats["promoted"] >= 2              # 32767 and 32768 needed the int32 tier

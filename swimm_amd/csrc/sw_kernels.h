@@ -39,6 +39,7 @@ struct PipeParams {
     int first_pass, last_pass;
     int32_t *out;               // packed mode: score row of this query; int32 mode: out32
     int goe, ge;                // open+extend, extend
+    unsigned long long *stamps; // diagnostic build only (-DSWIMM_STAMPS): per-wave-index cycle sums [16][8]
 };
 
 enum class Mode { PK16, I32, F16 };   // F16: packed binary16 first tier (pipeline kernel only)

@@ -32,6 +32,18 @@
 
 namespace swimm {
 
+// diagnostic build (make stamps): s_memtime sums per pipeline segment; never part of the product library
+#ifdef SWIMM_STAMPS
+#define STAMP(var)                                                                       \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 
@@ -194,9 +206,15 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
     uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, out_slot = 0;
     uint64_t bnd_off = 0;
     const uint8_t *dbp = nullptr;
+    uint32_t nwa = 0, nwb = 0;     // residues of the wave's next chunk, loaded one step ahead
+    bool have_next = false;
 
+#ifdef SWIMM_STAMPS
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, sumA = 0, sumB = 0, sumC = 0, sumD = 0, nact = 0;
+#endif
     for (int s = 0; s < nsteps; ++s) {
         const int c = s - k;                      // global chunk index of this wave in this step
+        STAMP(tA);
         if (c >= 0 && c < total && it < it_end) { // wave-uniform
             if (cc == 0) {                        // first chunk of a new item: reset the DP state
                 const Item iv = p.items[it];
@@ -207,14 +225,41 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
 #pragma unroll
                 for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
             }
-            // database residues of this chunk: 4 columns of the lane's sequence(s)
+            // database residues of this chunk: 4 columns of the lane's sequence(s).  They were requested one
+            // step ago (below): right after the barrier every wave would otherwise stall on this global load
+            // before it can form its first LDS address, with nothing else on the SIMD to cover it.
             uint32_t wa, wb = 0;
-            if (PK) {
-                // dbp came out of a descriptor in memory: tell the compiler it is global memory (no flat_load)
-                const unsigned long long w = *(const __attribute__((address_space(1))) unsigned long long *)(uintptr_t)(dbp + ((size_t)cc * 64 + lane) * 8);
-                wa = (uint32_t)w; wb = (uint32_t)(w >> 32);
+            if (!have_next) {
+                if (PK) {
+                    // dbp came out of a descriptor in memory: tell the compiler it is global memory (no flat_load)
+                    const unsigned long long w = *(const __attribute__((address_space(1))) unsigned long long *)(uintptr_t)(dbp + ((size_t)cc * 64 + lane) * 8);
+                    wa = (uint32_t)w; wb = (uint32_t)(w >> 32);
+                } else {
+                    wa = *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)(dbp + ((size_t)cc * 64 + lane) * 8 + half * 4);
+                }
             } else {
-                wa = *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)(dbp + ((size_t)cc * 64 + lane) * 8 + half * 4);
+                wa = nwa; wb = nwb;
+            }
+            {   // request the next chunk of this wave's stream (same item, or the first chunk of the next item)
+                const uint8_t *ndb = dbp;
+                uint32_t ncc = cc + 1, nhalf = half;
+                have_next = true;
+                if (ncc == nch) {
+                    if (it + 1 < it_end && c + 1 < total) {
+                        const Item niv = p.items[it + 1];
+                        ndb = p.groups[niv.group].db; ncc = 0; nhalf = niv.half;
+                    } else {
+                        have_next = false;
+                    }
+                }
+                if (have_next) {
+                    if (PK) {
+                        const unsigned long long w = *(const __attribute__((address_space(1))) unsigned long long *)(uintptr_t)(ndb + ((size_t)ncc * 64 + lane) * 8);
+                        nwa = (uint32_t)w; nwb = (uint32_t)(w >> 32);
+                    } else {
+                        nwa = *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)(ndb + ((size_t)ncc * 64 + lane) * 8 + nhalf * 4);
+                    }
+                }
             }
             // top boundary of the strip for these columns: H of the row above, F entering row 0
             uint2 bin[C];
@@ -231,6 +276,7 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
 #pragma unroll
                 for (int jj = 0; jj < C; ++jj) bin[jj] = src[jj * 64];
             }
+            STAMP(tB);
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) {
                 const uint32_t da = (wa >> (8 * jj)) & 0xffu;
@@ -273,6 +319,7 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
                 // all four columns' LDS reads and the kernel needs ~230 VGPRs (spills at 3 waves/SIMD)
                 __builtin_amdgcn_sched_barrier(0);
             }
+            STAMP(tC);
             if (++cc == nch) {   // item finished: every strip contributes its best (CPUsearch.c:670-676)
                 if (M == 2) {
                     const v2h b2 = __builtin_bit_cast(v2h, Ops::bits(best));
@@ -288,9 +335,23 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
                 cc = 0;
                 ++it;
             }
+#ifdef SWIMM_STAMPS
+            STAMP(tD);
+            sumA += tB - tA; sumB += tC - tB; sumC += tD - tC; nact++;
+#endif
         }
+#ifdef SWIMM_STAMPS
+        { unsigned long long t0, t1; STAMP(t0); __syncthreads(); STAMP(t1); sumD += t1 - t0; }
+#else
         __syncthreads();
+#endif
     }
+#ifdef SWIMM_STAMPS
+    if (p.stamps && lane == 0) {
+        atomicAdd(p.stamps + k * 8 + 0, sumA); atomicAdd(p.stamps + k * 8 + 1, sumB); atomicAdd(p.stamps + k * 8 + 2, sumC);
+        atomicAdd(p.stamps + k * 8 + 3, sumD); atomicAdd(p.stamps + k * 8 + 4, nact); atomicAdd(p.stamps + k * 8 + 5, (unsigned long long)nsteps);
+    }
+#endif
 }
 
 template <int T, int M>

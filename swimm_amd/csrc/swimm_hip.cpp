@@ -133,6 +133,7 @@ struct swimm_hip_ctx {
     DevBuf<uint32_t> d_gvalid;
     DevBuf<unsigned long long> d_keys;
     DevBuf<uint32_t> d_queue;
+    DevBuf<unsigned long long> d_stamps;   // diagnostic build only
     DevBuf<uint2> d_bnd2;               // pass boundary of the lane kernel (its own stream)
     DevBuf<uint32_t> d_satlist;
     // stats of the last search
@@ -333,7 +334,23 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
         p.first_pass = pass == 0;
         p.last_pass = pass == qp.passes - 1;
         p.out = out_row;
+#ifdef SWIMM_STAMPS
+        HIP_TRY(c->d_stamps.reserve(16 * 8));
+        HIP_TRY(hipMemsetAsync(c->d_stamps.p, 0, 16 * 8 * sizeof(unsigned long long), c->stream));
+        p.stamps = c->d_stamps.p;
+#endif
         HIP_TRY(launch_pipe(mode, qp.T, qp.W, pl.n_wg, p, c->stream));
+#ifdef SWIMM_STAMPS
+        {
+            unsigned long long h[16 * 8];
+            HIP_TRY(hipMemcpyAsync(h, c->d_stamps.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (int w = 0; w < qp.W; ++w)
+                fprintf(stderr, "stamps wave %2d: load/wait %8.0f  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active of %llu steps per wg)\n",
+                        w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4],
+                        (double)h[w * 8 + 3] / h[w * 8 + 4], h[w * 8 + 4] / pl.n_wg, h[w * 8 + 5] / pl.n_wg);
+        }
+#endif
         c->launches++;
         c->cells += pl.total_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * (mode == Mode::I32 ? 64 : 128);
     }

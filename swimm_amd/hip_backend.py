@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libswimm_hip.so")
+LIB_PATH = os.environ.get("SWIMM_HIP_LIB") or os.path.join(_HERE, "lib", "libswimm_hip.so")
 
 # every symbol include/swimm_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = (

@@ -97,7 +97,8 @@ int swimm_hip_last_stats(swimm_hip_ctx *ctx, double *kernel_ms, uint64_t *cells,
 /* Tuning knobs (optional).  key: "rows_per_wave" (16/32), "max_waves" (1..16), "force_i32" (0/1),
  * "wgs_per_cu" (0 = auto), "tail_mode" (0 = auto: unusually long groups go through the lane-systolic
  * kernel, 1 = every group, 2 = none), "f16" (1 = default: packed binary16 first tier, exact below 2048, with
- * int16 and int32 re-runs above; 0 = packed int16 first tier).  Unknown key -> error. */
+ * int16 and int32 re-runs above; 0 = packed int16 first tier), "sync" (0 = default: one workgroup barrier per chunk; 1 = neighbouring waves
+ * hand chunks over through LDS counters -- measured 1.5 % slower, kept for experiments).  Unknown key -> error. */
 int swimm_hip_set_option(swimm_hip_ctx *ctx, const char *key, int value);
 
 /* Whole-call drop-in with the argument list of mic_search_knc_ap_multiple_chunks

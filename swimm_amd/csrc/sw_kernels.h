@@ -39,6 +39,7 @@ struct PipeParams {
     int first_pass, last_pass;
     int32_t *out;               // packed mode: score row of this query; int32 mode: out32
     int goe, ge;                // open+extend, extend
+    uint32_t *err;              // pipeline watchdog: set non-zero if a bounded LDS wait ever expires
     unsigned long long *stamps; // diagnostic build only (-DSWIMM_STAMPS): per-wave-index cycle sums [16][8]
 };
 
@@ -74,10 +75,10 @@ struct LaneParams {
 size_t lane_lds_bytes();
 hipError_t launch_lane(Mode mode, int n_wg, const LaneParams &p, hipStream_t s);
 
-size_t pipe_lds_bytes(int rows_per_wave, int waves);
+size_t pipe_lds_bytes(int rows_per_wave, int waves, bool flag_sync);
 // registers / occupancy of one instantiation (for the host-side launch plan)
 hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, int *num_regs);
-hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, int n_wg, const PipeParams &p, hipStream_t s);
+hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, bool flag_sync, int n_wg, const PipeParams &p, hipStream_t s);
 
 // Re-tile one reference-layout chunk (sequences.c:506-526 byte interleave) into device groups.
 hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t vl_groups, uint32_t vl,

@@ -152,16 +152,36 @@ __host__ __device__ constexpr size_t round16(size_t x) { return (x + 15) & ~(siz
 // ds_read_b128 only when d == d' (mod 16)
 __host__ __device__ constexpr int prof_row_bytes(int rows) { return rows * 2 + 16; }
 
-size_t pipe_lds_bytes(int T, int W)
+// ring slots per wave: 2 with one workgroup barrier per chunk, kFlagRing when neighbouring waves hand
+// chunks over through LDS counters and may drift apart by that many chunks
+constexpr int kFlagRing = 4;
+size_t pipe_lds_bytes(int T, int W, bool flag_sync)
 {
-    return round16((size_t)kCodes * prof_row_bytes(T * W)) + (size_t)W * 2 * kChunkCols * 64 * sizeof(uint2);
+    return round16((size_t)kCodes * prof_row_bytes(T * W)) + (size_t)W * (flag_sync ? kFlagRing : 2) * kChunkCols * 64 * sizeof(uint2) + 128;
+}
+
+// bounded wait on an LDS counter another wave of the same workgroup advances (all waves of a workgroup are
+// resident, so this always makes progress; the bound only turns a logic error into an error code instead of a hang)
+__device__ __forceinline__ bool wait_counter_above(const uint32_t *ctr, uint32_t need)
+{
+    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+        if (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
 }
 
 // M: 0 = packed int16, 1 = int32 (one sequence per lane), 2 = packed f16
-template <int T, int M>
+// FS: false = one workgroup barrier per chunk (default); true = producer/consumer counters between
+//     neighbouring waves, ring of kFlagRing chunks.  Stamps show that the hardware issues the OLDEST ready
+//     wave first, so with a barrier the three waves of a SIMD finish a chunk one after the other (6 000 /
+//     9 700 / 14 100 cycles); letting the early waves run ahead through counters did NOT help (A/B in one
+//     process: 32.06 vs 31.55 ms on c2): the VALU is already kept as busy as three waves can keep it.
+template <int T, int M, bool FS>
 __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
 {
     constexpr bool PK = M != 1;
+    constexpr int R = FS ? kFlagRing : 2;
     typedef typename std::conditional<M == 0, OpsPK, typename std::conditional<M == 1, OpsI32, OpsF16>::type>::type Ops;
     typedef typename Ops::V V;
     constexpr int C = kChunkCols;
@@ -174,6 +194,9 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
     const int PS = prof_row_bytes(RW);
     unsigned char *prof_lds = smem;
     uint2 *ring = (uint2 *)(smem + round16((size_t)kCodes * PS));
+    uint32_t *prod = (uint32_t *)(ring + (size_t)W * R * C * 64);   // prod[k]: chunks wave k has published
+    uint32_t *cons = prod + 16;                                     // cons[k]: chunks wave k has taken from wave k-1
+    if (threadIdx.x < 32) prod[threadIdx.x] = 0;
 
     // stage this pass's window of the query profile: rows [r0, r0 + W*T) of all 25 codes
     {
@@ -195,7 +218,7 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
     const uint32_t it_end = p.wg_first[blockIdx.x + 1];
     uint32_t it = p.wg_first[blockIdx.x];
     const int total = (int)p.wg_chunks[blockIdx.x];
-    const int nsteps = total + W - 1;
+    const int nsteps = FS ? total : total + W - 1;
     const unsigned char *my_prof = prof_lds + k * T * 2;
 
     V H[T], E[T];
@@ -213,7 +236,7 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, sumA = 0, sumB = 0, sumC = 0, sumD = 0, nact = 0;
 #endif
     for (int s = 0; s < nsteps; ++s) {
-        const int c = s - k;                      // global chunk index of this wave in this step
+        const int c = FS ? s : s - k;             // global chunk index of this wave in this step
         STAMP(tA);
         if (c >= 0 && c < total && it < it_end) { // wave-uniform
             if (cc == 0) {                        // first chunk of a new item: reset the DP state
@@ -272,10 +295,17 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
                     for (int jj = 0; jj < C; ++jj) bin[jj] = p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane];
                 }
             } else {
-                const uint2 *src = ring + (size_t)(((k - 1) * 2 + (c & 1)) * C) * 64 + lane;
+                if (FS && !wait_counter_above(prod + (k - 1), (uint32_t)c + 1)) { if (lane == 0) atomicOr(p.err, 1u); return; }
+                const uint2 *src = ring + (size_t)(((k - 1) * R + (c & (R - 1))) * C) * 64 + lane;
 #pragma unroll
                 for (int jj = 0; jj < C; ++jj) bin[jj] = src[jj * 64];
+                if (FS) {   // the slot may be refilled once these reads have landed
+                    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+                    __hip_atomic_store(cons + k, (uint32_t)c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
+            // my own output slot of this chunk must have been drained by the next wave (it held chunk c - R)
+            if (FS && k < W - 1 && c >= R && !wait_counter_above(cons + (k + 1), (uint32_t)(c - R) + 1)) { if (lane == 0) atomicOr(p.err, 2u); return; }
             STAMP(tB);
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) {
@@ -313,12 +343,13 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
                 }
                 // bottom boundary of this column: to the next wave through LDS, or (last wave, more passes) to HBM
                 const uint2 bout = make_uint2(Ops::bits(H[T - 1]), Ops::bits(F));
-                if (k < W - 1) ring[(size_t)((k * 2 + (c & 1)) * C + jj) * 64 + lane] = bout;
+                if (k < W - 1) ring[(size_t)((k * R + (c & (R - 1))) * C + jj) * 64 + lane] = bout;
                 else if (!p.last_pass) p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = bout;
                 // keep one column's lookups in flight at a time: without this fence the scheduler hoists
                 // all four columns' LDS reads and the kernel needs ~230 VGPRs (spills at 3 waves/SIMD)
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (FS && k < W - 1) __hip_atomic_store(prod + k, (uint32_t)c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             STAMP(tC);
             if (++cc == nch) {   // item finished: every strip contributes its best (CPUsearch.c:670-676)
                 if (M == 2) {
@@ -341,9 +372,9 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
 #endif
         }
 #ifdef SWIMM_STAMPS
-        { unsigned long long t0, t1; STAMP(t0); __syncthreads(); STAMP(t1); sumD += t1 - t0; }
+        { unsigned long long t0, t1; STAMP(t0); if (!FS) __syncthreads(); STAMP(t1); sumD += t1 - t0; }
 #else
-        __syncthreads();
+        if (!FS) __syncthreads();
 #endif
     }
 #ifdef SWIMM_STAMPS
@@ -354,39 +385,45 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
 #endif
 }
 
-template <int T, int M>
+template <int T, int M, bool FS>
 static hipError_t launch_one(int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
-    const size_t lds = pipe_lds_bytes(T, W);
-    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = pipe_lds_bytes(T, W, FS);
+    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, M, FS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sw_pipe_kernel<T, M>), dim3(n_wg), dim3(W * 64), lds, s, p);
+    hipLaunchKernelGGL((sw_pipe_kernel<T, M, FS>), dim3(n_wg), dim3(W * 64), lds, s, p);
     return hipGetLastError();
 }
 
-template <int T>
+template <int T, bool FS>
 static hipError_t launch_mode(Mode mode, int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
-    if (mode == Mode::PK16) return launch_one<T, 0>(W, n_wg, p, s);
-    if (mode == Mode::I32) return launch_one<T, 1>(W, n_wg, p, s);
-    return launch_one<T, 2>(W, n_wg, p, s);
+    if (mode == Mode::PK16) return launch_one<T, 0, FS>(W, n_wg, p, s);
+    if (mode == Mode::I32) return launch_one<T, 1, FS>(W, n_wg, p, s);
+    return launch_one<T, 2, FS>(W, n_wg, p, s);
 }
 
-hipError_t launch_pipe(Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t s)
+hipError_t launch_pipe(Mode mode, int T, int W, bool flag_sync, int n_wg, const PipeParams &p, hipStream_t s)
 {
     if (W < 1 || W > kMaxWaves || n_wg < 1) return hipErrorInvalidValue;
-    if (T == 32) return launch_mode<32>(mode, W, n_wg, p, s);
-    if (T == 24) return launch_mode<24>(mode, W, n_wg, p, s);
-    if (T == 16) return launch_mode<16>(mode, W, n_wg, p, s);
+    if (flag_sync) {
+        if (T == 32) return launch_mode<32, true>(mode, W, n_wg, p, s);
+        if (T == 24) return launch_mode<24, true>(mode, W, n_wg, p, s);
+        if (T == 16) return launch_mode<16, true>(mode, W, n_wg, p, s);
+    } else {
+        if (T == 32) return launch_mode<32, false>(mode, W, n_wg, p, s);
+        if (T == 24) return launch_mode<24, false>(mode, W, n_wg, p, s);
+        if (T == 16) return launch_mode<16, false>(mode, W, n_wg, p, s);
+    }
     return hipErrorInvalidValue;
 }
 
 template <int T>
 static const void *kernel_ptr(Mode mode)
 {
-    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0>;
-    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1>;
-    return (const void *)sw_pipe_kernel<T, 2>;
+    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0, true>;
+    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1, true>;
+    return (const void *)sw_pipe_kernel<T, 2, true>;
 }
 
 hipError_t pipe_kernel_attributes(Mode mode, int T, int *num_regs)

@@ -108,6 +108,7 @@ struct swimm_hip_ctx {
     // options
     int opt_T = 32, opt_maxW = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
+    int opt_sync = 0;                   // 0: one barrier per chunk (default, measured faster); 1: counter hand-over between neighbouring waves
     int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
     // queries (host copies; profiles are built per search because T/W may change)
     std::vector<int8_t> qcodes;
@@ -133,6 +134,7 @@ struct swimm_hip_ctx {
     DevBuf<uint32_t> d_gvalid;
     DevBuf<unsigned long long> d_keys;
     DevBuf<uint32_t> d_queue;
+    DevBuf<uint32_t> d_err;             // pipeline watchdog word
     DevBuf<unsigned long long> d_stamps;   // diagnostic build only
     DevBuf<uint2> d_bnd2;               // pass boundary of the lane kernel (its own stream)
     DevBuf<uint32_t> d_satlist;
@@ -175,7 +177,7 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
     int regs = 0;
     HIP_TRY(pipe_kernel_attributes(mode, T, &regs));
     const int waves_cu = 4 * regs_to_waves_per_simd(regs);
-    const size_t lds = pipe_lds_bytes(T, W);
+    const size_t lds = pipe_lds_bytes(T, W, c->opt_sync != 0);
     int n = std::min(waves_cu / W, (int)(163840 / lds));
     if (c->opt_wgs_per_cu > 0) n = c->opt_wgs_per_cu;
     *out = std::max(1, n);
@@ -339,7 +341,8 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
         HIP_TRY(hipMemsetAsync(c->d_stamps.p, 0, 16 * 8 * sizeof(unsigned long long), c->stream));
         p.stamps = c->d_stamps.p;
 #endif
-        HIP_TRY(launch_pipe(mode, qp.T, qp.W, pl.n_wg, p, c->stream));
+        p.err = c->d_err.p;
+        HIP_TRY(launch_pipe(mode, qp.T, qp.W, c->opt_sync != 0, pl.n_wg, p, c->stream));
 #ifdef SWIMM_STAMPS
         {
             unsigned long long h[16 * 8];
@@ -455,6 +458,8 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
         HIP_TRY(c->d_bnd2.reserve(need_bnd2));
         HIP_TRY(c->d_queue.reserve(1));
     }
+    HIP_TRY(c->d_err.reserve(1));
+    HIP_TRY(hipMemsetAsync(c->d_err.p, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
@@ -543,6 +548,9 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->kernel_ms = ms;
+    uint32_t werr = 0;
+    HIP_TRY(hipMemcpy(&werr, c->d_err.p, sizeof werr, hipMemcpyDeviceToHost));
+    if (werr) return fail("pipeline watchdog expired (code %u): results discarded", werr);
     return 0;
 }
 
@@ -595,7 +603,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
     c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
-    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_queue.release(); c->d_bnd2.release(); c->d_satlist.release();
+    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_queue.release(); c->d_err.release(); c->d_bnd2.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
@@ -829,6 +837,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         c->opt_maxW = value;
     } else if (!strcmp(key, "force_i32")) {
         c->opt_force_i32 = value != 0;
+    } else if (!strcmp(key, "sync")) {
+        c->opt_sync = value != 0;
     } else if (!strcmp(key, "f16")) {
         c->opt_f16 = value != 0;
     } else if (!strcmp(key, "tail_mode")) {

@@ -45,7 +45,8 @@ def test_golden_all_cases(searcher, gin, golden):
 
 @pytest.mark.parametrize("opts", [{"force_i32": 1}, {"rows_per_wave": 16}, {"max_waves": 1}, {"max_waves": 5, "wgs_per_cu": 1},
                                   {"tail_mode": 1}, {"tail_mode": 2}, {"tail_mode": 1, "rows_per_wave": 16}, {"rows_per_wave": 24},
-                                  {"f16": 1}, {"f16": 1, "tail_mode": 2}, {"f16": 1, "rows_per_wave": 24, "tail_mode": 2}])
+                                  {"f16": 0}, {"f16": 0, "tail_mode": 2}, {"f16": 1, "rows_per_wave": 24, "tail_mode": 2},
+                                  {"sync": 1}, {"sync": 1, "tail_mode": 2, "f16": 0}, {"sync": 1, "tail_mode": 2, "max_waves": 3}])
 def test_golden_kernel_variants(gin, golden, opts):
     q, pp, chunked = gin
     N = golden["search"]["n_sequences"]

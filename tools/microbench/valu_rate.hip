@@ -5,6 +5,7 @@
 #include <vector>
 #include <string>
 
+__device__ unsigned long long g_clk[2];
 #define ITER 2048
 #define OPS_PER_ITER 16
 
@@ -12,6 +13,7 @@
     __global__ void __launch_bounds__(256) k_##NAME(uint32_t *out, uint32_t seed)                    \
     {                                                                                                \
         uint32_t r[8], y = seed + threadIdx.x, z = seed * 3 + 1;                                     \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime(); \
         for (int i = 0; i < 8; ++i) r[i] = threadIdx.x * 7 + i;                                      \
         for (int it = 0; it < ITER; ++it) {                                                          \
             _Pragma("unroll") for (int u = 0; u < OPS_PER_ITER; ++u)                                 \
@@ -20,6 +22,10 @@
         uint32_t acc = 0;                                                                            \
         for (int i = 0; i < 8; ++i) acc ^= r[i];                                                     \
         out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                                            \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                   \
+            g_clk[0] = __builtin_amdgcn_s_memtime() - t0;                                            \
+            g_clk[1] = __builtin_amdgcn_s_memrealtime() - w0;                                        \
+        }                                                                                            \
     }
 
 DEFINE_KERNEL(add_u32, "v_add_u32 %0, %0, %1")
@@ -63,10 +69,11 @@ int main()
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     printf("device %s, %d CUs, clock %d kHz\n", prop.gcnArchName, cus, prop.clockRate);
-    printf("%-22s %10s %10s %10s   (cycles per wave64 instruction per SIMD at the nominal 2.4 GHz)\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD");
+    printf("%-22s %8s %8s %8s %8s %8s %8s   cycles per wave64 instruction per SIMD at the MEASURED shader clock (s_memtime / s_memrealtime); last column: that clock in GHz at 8 w/SIMD\n", "instruction", "1 w/SIMD", "2", "3", "4", "6", "8");
     for (auto &e : ks) {
         printf("%-22s", e.name);
-        for (int w : {1, 2, 4}) {
+        double ghz = 0;
+        for (int w : {1, 2, 3, 4, 6, 8}) {
             const int blocks = cus * w;   // 256-thread blocks: one wave per SIMD each
             hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, 1u);
             hipDeviceSynchronize();
@@ -77,10 +84,13 @@ int main()
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
             const double instr_per_simd = 5.0 * w * (double)ITER * OPS_PER_ITER;
-            const double cyc = ms * 1e-3 * 2.4e9 / instr_per_simd;
-            printf(" %10.2f", cyc);
+            unsigned long long clk[2];
+            hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof clk);
+            ghz = (double)clk[0] / (double)clk[1] * 0.1;   // s_memrealtime ticks at 100 MHz
+            const double cyc = ms * 1e-3 * ghz * 1e9 / instr_per_simd;
+            printf(" %8.2f", cyc);
         }
-        printf("\n");
+        printf("   %.2f GHz\n", ghz);
     }
     return 0;
 }

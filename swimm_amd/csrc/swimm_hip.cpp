@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <queue>
@@ -102,11 +103,13 @@ struct swimm_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // lane-systolic tail runs beside the bulk kernel
-    hipEvent_t ev_ready = nullptr, ev_tail = nullptr;
+    hipStream_t stream3 = nullptr;      // promotion re-runs
+    hipEvent_t ev_ready = nullptr, ev_tail = nullptr, ev_tail3 = nullptr;
+    std::vector<hipEvent_t> ev_query;   // [2q] bulk done, [2q+1] tail done
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cu = 0;
     // options
-    int opt_T = 32, opt_maxW = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;
+    int opt_T = 0, opt_maxW = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;   // 0 = chosen per query
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
     int opt_sync = 0;                   // 0: one barrier per chunk (default, measured faster); 1: counter hand-over between neighbouring waves
     int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
@@ -137,6 +140,8 @@ struct swimm_hip_ctx {
     DevBuf<uint32_t> d_err;             // pipeline watchdog word
     DevBuf<unsigned long long> d_stamps;   // diagnostic build only
     DevBuf<uint2> d_bnd2;               // pass boundary of the lane kernel (its own stream)
+    DevBuf<uint2> d_bnd3;               // ... of the promotion re-runs (third stream)
+    DevBuf<LaneItem> d_rerun_items;
     DevBuf<uint32_t> d_satlist;
     // stats of the last search
     double kernel_ms = 0;
@@ -159,19 +164,6 @@ int regs_to_waves_per_simd(int regs)
 }
 
 // T rows per wave, W waves per workgroup, number of passes for a query of m rows
-QueryPlan choose_plan(const swimm_hip_ctx *c, int m)
-{
-    QueryPlan q{};
-    q.T = (c->opt_T == 16 || c->opt_T == 24) ? c->opt_T : 32;
-    int maxW = (q.T == 32) ? 12 : 16;       // __launch_bounds__ of the instantiations
-    if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
-    const int strips = std::max(1, (m + q.T - 1) / q.T);
-    q.passes = (strips + maxW - 1) / maxW;
-    q.W = (strips + q.passes - 1) / q.passes;
-    q.mpad = (uint32_t)(q.passes * q.W * q.T);
-    return q;
-}
-
 int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
 {
     int regs = 0;
@@ -181,6 +173,42 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
     int n = std::min(waves_cu / W, (int)(163840 / lds));
     if (c->opt_wgs_per_cu > 0) n = c->opt_wgs_per_cu;
     *out = std::max(1, n);
+    return 0;
+}
+
+// measured issue interval of a half-rate VALU instruction (cycles) by waves per SIMD
+// (tools/microbench/valu_rate, profiles/r01_valu_issue_rates.txt)
+double issue_cycles(double waves_per_simd)
+{
+    static const double w[] = {1, 2, 3, 4, 6, 8}, cyc[] = {5.70, 4.71, 4.48, 4.40, 4.27, 4.22};
+    if (waves_per_simd <= 1) return cyc[0] / std::max(waves_per_simd, 0.25);   // a SIMD without a wave does nothing
+    for (int i = 1; i < 6; ++i)
+        if (waves_per_simd <= w[i]) return cyc[i - 1] + (cyc[i] - cyc[i - 1]) * (waves_per_simd - w[i - 1]) / (w[i] - w[i - 1]);
+    return cyc[5];
+}
+
+// Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the candidate with the
+// best modelled VALU efficiency = (real rows / padded rows) x (issue rate at the occupancy it reaches) x
+// (row instructions / (row + per-column instructions)).  Short queries gain up to 40 % over "always T=32"
+// (m=189: 6 waves of 32 rows -> 8 of 24, two workgroups per CU).
+int choose_plan(const swimm_hip_ctx *c, Mode mode, int m, int forced_T, QueryPlan *out)
+{
+    double best_eff = -1;
+    for (int T : {32, 24, 16}) {
+        if (forced_T && T != forced_T) continue;
+        int maxW = (T == 32) ? 12 : 16;       // __launch_bounds__ of the instantiations
+        if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
+        const int strips = std::max(1, (m + T - 1) / T);
+        const int passes = (strips + maxW - 1) / maxW;
+        const int W = (strips + passes - 1) / passes;
+        int per_cu = 1;
+        if (wgs_per_cu(c, mode, T, W, &per_cu)) return 1;
+        const double eff = (double)m / ((double)passes * W * T) * (4.22 / issue_cycles(per_cu * W / 4.0)) * (8.5 * T / (8.5 * T + 12.0));
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            out->T = T; out->W = W; out->passes = passes; out->mpad = (uint32_t)(passes * W * T);
+        }
+    }
     return 0;
 }
 
@@ -262,8 +290,9 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, int n_wg)
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->groups[a].ncols > c->groups[b].ncols; });
     uint64_t rest = c->total_cols;
+    (void)n_wg;   // the yardstick is the load of a CU, however many workgroups share it
     for (uint32_t g : order) {
-        const double mean = (double)rest / n_wg;
+        const double mean = (double)rest / c->num_cu;
         if ((double)c->groups[g].ncols <= 0.5 * mean) break;
         is_tail[g] = 1;
         rest -= c->groups[g].ncols;
@@ -361,31 +390,31 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
 }
 
 // all passes of the lane-systolic kernel over one work list for one query
-int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row, hipStream_t st)
+int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row, hipStream_t st,
+                    DevBuf<uint2> &bnd, uint32_t *queue_word)
 {
     if (ll.n == 0) return 0;
     const int rows_pass = 64 * kLaneRows;
     const int passes = (m + rows_pass - 1) / rows_pass;
-    if (passes > 1) HIP_TRY(c->d_bnd2.reserve(std::max<uint64_t>(ll.cols, 1)));
-    HIP_TRY(c->d_queue.reserve(1));
+    if (passes > 1 && bnd.cap < ll.cols) return fail("internal: lane boundary buffer too small (%zu < %llu)", bnd.cap, (unsigned long long)ll.cols);
     // 4 waves per workgroup; enough workgroups to fill the chip (58 VGPRs: 8 waves/SIMD, 26 KB LDS: 6 per CU)
     const int n_wg = (int)std::max<uint64_t>(1, std::min<uint64_t>((ll.n + 3) / 4, (uint64_t)c->num_cu * 6));
     for (int pass = 0; pass < passes; ++pass) {
         LaneParams p{};
         p.items = ll.items.p;
         p.n_items = ll.n;
-        p.queue = c->d_queue.p;
+        p.queue = queue_word;
         p.prof = c->d_prof.p + qp.prof_off;
         p.prof_stride = qp.mpad;
         p.r0 = (uint32_t)(pass * rows_pass);
         p.rows = (uint32_t)std::min(rows_pass, m - pass * rows_pass);
-        p.bnd = c->d_bnd2.p;
+        p.bnd = bnd.p;
         p.first_pass = pass == 0;
         p.last_pass = pass == passes - 1;
         p.out = out_row;
         p.goe = c->open_gap + c->extend_gap;
         p.ge = c->extend_gap;
-        HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(queue_word, 0, sizeof(uint32_t), st));
         HIP_TRY(launch_lane(mode, n_wg, p, st));
         c->launches++;
         c->cells += ll.cell_cols * (uint64_t)rows_pass * (mode == Mode::PK16 ? 2 : 1);
@@ -419,10 +448,21 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
     // query's end are zero, like the reference's dummy row 23
+    const Mode main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 ? Mode::F16 : Mode::PK16);
+    // a database with a long-sequence tail keeps T=32: 3 bulk waves x 144 VGPRs leave exactly the 80 registers
+    // per SIMD lane that a lane-systolic wave needs to run beside them
+    int forced_T = (c->opt_T == 16 || c->opt_T == 24 || c->opt_T == 32) ? c->opt_T : 0;
+    if (!forced_T && c->opt_tail_mode != 2 && main_mode != Mode::I32) {
+        uint32_t longest = 0;
+        for (const GroupDesc &g : c->groups) longest = std::max(longest, g.ncols);
+        if (c->opt_tail_mode == 1 || (double)longest > 0.5 * (double)c->total_cols / c->num_cu) forced_T = 32;
+    }
     std::vector<QueryPlan> qps(qn);
     size_t prof_elems = 0;
     for (uint32_t q = 0; q < qn; ++q) {
-        qps[q] = choose_plan(c, c->qm[q]);
+        if (choose_plan(c, main_mode, c->qm[q], forced_T, &qps[q])) return 1;
+        if (getenv("SWIMM_HIP_DEBUG"))
+            fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (forced_T=%d)\n", q, c->qm[q], qps[q].T, qps[q].W, qps[q].passes, forced_T);
         const uint32_t lane_rows = (uint32_t)((c->qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
         qps[q].mpad = std::max(qps[q].mpad, lane_rows);
         qps[q].prof_off = prof_elems;
@@ -441,7 +481,6 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
     HIP_TRY(hipMemsetAsync(c->d_scores.p, 0, (size_t)qn * S * sizeof(int32_t), c->stream));
 
-    const Mode main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 ? Mode::F16 : Mode::PK16);
     // buffers that later launches grow are sized up front: a reallocation in the middle of the
     // two-stream phase would free memory a kernel in flight still uses
     {
@@ -456,58 +495,89 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
         }
         HIP_TRY(c->d_bnd.reserve(need_bnd));
         HIP_TRY(c->d_bnd2.reserve(need_bnd2));
-        HIP_TRY(c->d_queue.reserve(1));
+        HIP_TRY(c->d_queue.reserve(2));                      // [0] tail stream, [1] promotion stream
+        HIP_TRY(c->d_satlist.reserve((size_t)(1u << 16) + 1));
+        HIP_TRY(c->d_rerun_items.reserve(4096));
+        HIP_TRY(c->d_bnd3.reserve((size_t)1 << 22));
     }
     HIP_TRY(c->d_err.reserve(1));
     HIP_TRY(hipMemsetAsync(c->d_err.p, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
-    for (uint32_t q = 0; q < qn; ++q) {
+    HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
+    while (c->ev_query.size() < 2 * (size_t)qn) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_query.push_back(e);
+    }
+    // Longest query first: its promotion re-runs (a handful of long serial chains on stream 3) then overlap
+    // the bulk kernels of the shorter queries instead of running alone at the end.
+    for (uint32_t k = 0; k < qn; ++k) {
+        const uint32_t q = qn - 1 - k;                 // queries arrive sorted by ascending length
         int per_cu = 1;
         if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
         DbPlan *dp = nullptr;
         if (get_db_plan(c, main_mode, c->num_cu * per_cu, &dp)) return 1;
         int32_t *row = c->d_scores.p + (size_t)q * S;
+        if (getenv("SWIMM_HIP_DEBUG"))
+            fprintf(stderr, "swimm_hip: query %u: %d workgroups (%d per CU), %u tail items, main %s\n", q, dp->main.n_wg, per_cu, dp->tail.n, dp->have_main ? "yes" : "no");
         // the long-sequence tail (a few long serial chains, one wave each) runs on its own stream beside the
         // bulk kernel: 3 bulk waves (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly
-        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row, c->stream2)) return 1;
+        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row, c->stream2, c->d_bnd2, c->d_queue.p)) return 1;
         if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row)) return 1;
+        HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
+        HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->stream2));
     }
-    HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
     // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
     // f16 results >= 2048 are re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; each
-    // re-run is a lane-systolic item (one wave per alignment)
+    // re-run is a lane-systolic item (one wave per alignment), issued on stream 3 as soon as the query's own
+    // kernels are done
     if (main_mode != Mode::I32) {
         const uint32_t cap = 1u << 16;
         std::vector<uint32_t> list;
         auto collect = [&](uint32_t q, int thr, std::vector<uint32_t> &out) -> int {
             int32_t *row = c->d_scores.p + (size_t)q * S;
-            HIP_TRY(c->d_satlist.reserve((size_t)cap + 1));
             uint32_t *d_count = c->d_satlist.p + cap;
-            HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
-            HIP_TRY(launch_collect_saturated(row, S, thr, c->d_satlist.p, d_count, cap, c->stream));
+            HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream3));
+            HIP_TRY(launch_collect_saturated(row, S, thr, c->d_satlist.p, d_count, cap, c->stream3));
             uint32_t count = 0;
-            HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream3));
+            HIP_TRY(hipStreamSynchronize(c->stream3));
             if (count > cap) return fail("more than %u alignments of query %u left the %s range: use force_i32", cap, q, thr == 2048 ? "f16" : "int16");
             out.resize(count);
-            if (count) HIP_TRY(hipMemcpy(out.data(), c->d_satlist.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (count) {
+                HIP_TRY(hipMemcpyAsync(out.data(), c->d_satlist.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream3));
+                HIP_TRY(hipStreamSynchronize(c->stream3));
+            }
             return 0;
         };
         auto rerun = [&](uint32_t q, Mode mode, std::vector<LaneItem> &items) -> int {
             if (items.empty()) return 0;
+            std::stable_sort(items.begin(), items.end(), [](const LaneItem &a, const LaneItem &b) { return a.ncols > b.ncols; });
+            uint64_t cols = 0;
+            for (LaneItem &it : items) { it.bnd_off = (uint32_t)cols; cols += it.ncols; }
+            if (items.size() > c->d_rerun_items.cap || cols > c->d_bnd3.cap) {
+                // growing a buffer frees the old one, which waits for the whole device: rare (first big batch)
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(c->d_rerun_items.reserve(items.size() * 2));
+                HIP_TRY(c->d_bnd3.reserve(cols * 2));
+            }
+            HIP_TRY(hipMemcpyAsync(c->d_rerun_items.p, items.data(), items.size() * sizeof(LaneItem), hipMemcpyHostToDevice, c->stream3));
+            HIP_TRY(hipStreamSynchronize(c->stream3));       // `items` is a host temporary
             LaneList ll;
-            if (upload_lane_items(c, items, ll)) return 1;
-            HIP_TRY(c->d_bnd2.reserve(ll.cols));
-            const int rc = run_lane_passes(c, mode, qps[q], c->qm[q], ll, c->d_scores.p + (size_t)q * S, c->stream);
-            if (rc == 0) HIP_TRY(hipStreamSynchronize(c->stream));
-            ll.release();
+            ll.items.p = c->d_rerun_items.p; ll.items.cap = c->d_rerun_items.cap;
+            ll.n = (uint32_t)items.size(); ll.cols = cols; ll.cell_cols = cols;
+            const int rc = run_lane_passes(c, mode, qps[q], c->qm[q], ll, c->d_scores.p + (size_t)q * S, c->stream3, c->d_bnd3, c->d_queue.p + 1);
+            ll.items.p = nullptr; ll.items.cap = 0;           // borrowed
             return rc;
         };
-        for (uint32_t q = 0; q < qn; ++q) {
+        for (uint32_t k = 0; k < qn; ++k) {
+            const uint32_t q = qn - 1 - k;
             const long bound = (long)c->qm[q] * c->max_pos;     // no alignment of this query can score more
+            if (!((main_mode == Mode::F16 && bound >= 2048) || bound >= 32767)) continue;
+            HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_query[2 * q], 0));
+            HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_query[2 * q + 1], 0));
             if (main_mode == Mode::F16 && bound >= 2048) {
                 if (collect(q, 2048, list)) return 1;
                 std::vector<LaneItem> items;
@@ -543,6 +613,10 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             if (rerun(q, Mode::I32, items)) return 1;
         }
     }
+    HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
+    HIP_TRY(hipEventRecord(c->ev_tail3, c->stream3));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail3, 0));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0;
@@ -587,6 +661,7 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+        hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) {
@@ -603,12 +678,15 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
     c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
-    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_queue.release(); c->d_err.release(); c->d_bnd2.release(); c->d_satlist.release();
+    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_queue.release(); c->d_err.release(); c->d_bnd2.release(); c->d_bnd3.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->ev_tail3) (void)hipEventDestroy(c->ev_tail3);
+    for (hipEvent_t e : c->ev_query) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -830,7 +908,7 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail("swimm_hip_set_option: NULL argument");
     if (!strcmp(key, "rows_per_wave")) {
-        if (value != 16 && value != 24 && value != 32) return fail("rows_per_wave must be 16, 24 or 32");
+        if (value != 0 && value != 16 && value != 24 && value != 32) return fail("rows_per_wave must be 0 (auto), 16, 24 or 32");
         c->opt_T = value;
     } else if (!strcmp(key, "max_waves")) {
         if (value < 0 || value > kMaxWaves) return fail("max_waves must be 0..%d", kMaxWaves);

@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--wgs-per-cu", type=int, default=0)
     ap.add_argument("--per-query", action="store_true")
     ap.add_argument("--only", type=str, default="", help="comma-separated indices into the config's query list")
+    ap.add_argument("--opt", action="append", default=[], help="key=value for swimm_hip_set_option (repeatable)")
     args = ap.parse_args()
     cfg = dict(CFG[args.config])
     if args.only:
@@ -82,6 +83,9 @@ def main():
         for k, v in (("rows_per_wave", args.rows_per_wave), ("max_waves", args.max_waves), ("wgs_per_cu", args.wgs_per_cu)):
             if v:
                 s.set_option(k, v)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            s.set_option(k, int(v))
         for c in chunks.chunks:
             s.add_chunk(c["b"], c["n"], c["disp"], 128, c["first_group"])
         if args.per_query:

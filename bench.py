@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # every instruction of the inner loop is VOP3P / 3-source: 4 cycles per wave64 instruction on a SIMD
 # (tools/microbench/valu_rate, profiles/r01_valu_issue_rates.txt) -> 1024 SIMDs x 2.4 GHz / 4
 VALU_PEAK_GINSTR = 256 * 4 * 2.4e9 / 4 / 1e9
-INSTR_PER_WAVE_COLUMN = 32 * 8.5 + 10              # T=32 rows x (7.5 packed-f16 ops + 1 v_perm) + per-column overhead
+INSTR_PER_ROW, INSTR_PER_COLUMN = 8.5, 10          # 7.5 packed-f16 ops + 1 v_perm per packed row; per-column overhead
 
 
 def build_shard(seed: int, scale: float):
@@ -230,7 +230,9 @@ def main():
         kernel_gcups = cells_real / (k_ms * 1e-3) / 1e9
         # VALU ceiling (SURVEY 8d ceiling (1)): wave-instructions issued per second vs the half-rate issue peak
         cells_padded = float(stats["cells"])
-        n_instr = cells_padded / (128 * 32) * INSTR_PER_WAVE_COLUMN
+        plan = searcher.last_plan(0)
+        T = plan["rows_per_wave"]
+        n_instr = cells_padded / (128 * T) * (T * INSTR_PER_ROW + INSTR_PER_COLUMN)
         ginstr = n_instr / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
@@ -238,16 +240,16 @@ def main():
             "vs_baseline": None, "dtype": "f16 (exact integers < 2048) -> int16 -> int32", "data": "synthetic",
             "config": {"workload": "c2: 375-aa query x 1M synthetic proteins per GPU, BLOSUM62 g10 e2, top-20",
                        "query_len": m_real, "db_sequences_per_gpu": shard["n"], "db_residues_per_gpu": shard["residues"],
-                       "parallelism": f"db-shard x{world}", "rows_per_wave": 32, "scale": args.scale,
+                       "parallelism": f"db-shard x{world}", "plan": searcher.last_plan(0), "scale": args.scale,
                        "topr_exchange": "none" if world == 1 else ("rccl all_gather" if rccl is not None else "gloo all_gather")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "sw_pipe_kernel<32, packed f16>", "kernel_ms": round(k_ms / launches, 4),
+                         "kernel": "sw_pipe_kernel<T, packed f16>", "kernel_ms": round(k_ms / launches, 4),
                          "alg_bytes_per_launch": alg_bytes,
                          "note": "VALU-bound kernel: see valu_roofline; HBM carries only the DB residues (1/m B per cell)"},
             "valu_roofline": {"achieved": round(ginstr, 1), "peak": round(VALU_PEAK_GINSTR, 1), "unit": "G wave-instr/s",
                               "frac": round(ginstr / VALU_PEAK_GINSTR, 4), "kernel_only_gcups": round(kernel_gcups, 2),
-                              "padded_cells": cells_padded, "instr_per_wave_column": INSTR_PER_WAVE_COLUMN},
+                              "padded_cells": cells_padded, "instr_per_wave_column": T * INSTR_PER_ROW + INSTR_PER_COLUMN},
             "search_call_ms": round(float(np.mean(wts)) * 1e3, 4),
             "h2d_upload_s": round(t_up, 3), "datagen_s": round(shard["gen_s"], 2),
             "top1": [int(top_s[0]), int(top_i[0])],

@@ -94,6 +94,10 @@ int swimm_hip_search_topr(swimm_hip_ctx *ctx, uint32_t r, uint64_t n_valid, int3
 int swimm_hip_last_stats(swimm_hip_ctx *ctx, double *kernel_ms, uint64_t *cells, uint64_t *promoted,
                          uint32_t *launches);
 
+/* Launch plan the last search used for query `q` (after the ascending-length order of set_queries):
+ * rows of the query held per wavefront, wavefronts per workgroup, passes over the database. */
+int swimm_hip_last_plan(swimm_hip_ctx *ctx, uint32_t q, int *rows_per_wave, int *waves, int *passes);
+
 /* Tuning knobs (optional).  key: "rows_per_wave" (0 = chosen per query, 16/24/32), "max_waves" (1..16), "force_i32" (0/1),
  * "wgs_per_cu" (0 = auto), "tail_mode" (0 = auto: unusually long groups go through the lane-systolic
  * kernel, 1 = every group, 2 = none), "f16" (1 = default: packed binary16 first tier, exact below 2048, with

@@ -52,6 +52,7 @@ int swimm_hip_load(swimm_hip_api *api, char *err, unsigned long err_len)
     BIND(search, "swimm_hip_search");
     BIND(search_topr, "swimm_hip_search_topr");
     BIND(last_stats, "swimm_hip_last_stats");
+    BIND(last_plan, "swimm_hip_last_plan");
     BIND(set_option, "swimm_hip_set_option");
     if (api->abi_version() != SWIMM_HIP_ABI_VERSION) {
         snprintf(err, err_len, "SWIMM: %s has ABI version %d, this program needs %d", path, api->abi_version(), SWIMM_HIP_ABI_VERSION);

@@ -17,6 +17,7 @@ typedef struct {
     int (*search)(swimm_hip_ctx *, int32_t *, uint64_t, double *);
     int (*search_topr)(swimm_hip_ctx *, uint32_t, uint64_t, int32_t *, int64_t *, double *);
     int (*last_stats)(swimm_hip_ctx *, double *, uint64_t *, uint64_t *, uint32_t *);
+    int (*last_plan)(swimm_hip_ctx *, uint32_t, int *, int *, int *);
     int (*set_option)(swimm_hip_ctx *, const char *, int);
 } swimm_hip_api;
 

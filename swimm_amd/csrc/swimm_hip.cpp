@@ -146,6 +146,7 @@ struct swimm_hip_ctx {
     // stats of the last search
     double kernel_ms = 0;
     uint64_t cells = 0, promoted = 0, promoted16 = 0;
+    std::vector<QueryPlan> last_plans;
     uint32_t launches = 0;
 };
 
@@ -476,6 +477,7 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             for (uint32_t r = 0; r < c->qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + d];
         }
     }
+    c->last_plans = qps;
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
@@ -901,6 +903,16 @@ int swimm_hip_last_stats(swimm_hip_ctx *c, double *kernel_ms, uint64_t *cells, u
     if (cells) *cells = c->cells;
     if (promoted) *promoted = c->promoted;
     if (launches) *launches = c->launches;
+    return 0;
+}
+
+int swimm_hip_last_plan(swimm_hip_ctx *c, uint32_t q, int *rows_per_wave, int *waves, int *passes)
+{
+    if (!c) return fail("swimm_hip_last_plan: NULL ctx");
+    if (q >= c->last_plans.size()) return fail("swimm_hip_last_plan: query %u was not part of the last search", q);
+    if (rows_per_wave) *rows_per_wave = c->last_plans[q].T;
+    if (waves) *waves = c->last_plans[q].W;
+    if (passes) *passes = c->last_plans[q].passes;
     return 0;
 }
 

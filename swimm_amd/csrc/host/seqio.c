@@ -114,12 +114,20 @@ int swimm_fasta_read(const char *path, swimm_fasta *out)
             k++;
             in_record = 1;
         } else if (in_record) {
-            for (size_t j = i; j < e; ++j) {
-                unsigned char ch = (unsigned char)buf[j];
-                if (ch == '\r' || ch == ' ' || ch == '\t') continue;
-                seqbuf[w++] = (char)ch;
-                lengths[k - 1]++;
-                total++;
+            size_t le = e;
+            while (le > i && (buf[le - 1] == '\r' || buf[le - 1] == ' ' || buf[le - 1] == '\t')) le--;
+            const size_t n = le - i;
+            if (n && !memchr(buf + i, ' ', n) && !memchr(buf + i, '\t', n)) {   // the usual case: one memcpy per line
+                memcpy(seqbuf + w, buf + i, n);
+                w += n; lengths[k - 1] += (uint32_t)n; total += n;
+            } else {
+                for (size_t j = i; j < le; ++j) {
+                    unsigned char ch = (unsigned char)buf[j];
+                    if (ch == ' ' || ch == '\t' || ch == '\r') continue;
+                    seqbuf[w++] = (char)ch;
+                    lengths[k - 1]++;
+                    total++;
+                }
             }
         }
         i = e + 1;
@@ -207,10 +215,23 @@ int swimm_preprocess_db(const char *fasta_path, const char *out_prefix, uint64_t
     for (uint64_t i = 0; i < f.count; ++i) l16[i] = (uint16_t)f.lengths[order[i]];
     fwrite(l16, sizeof(uint16_t), f.count, fs);
     free(l16);
-    for (uint64_t i = 0; i < f.count; ++i) {
-        uint64_t s = order[i];
-        swimm_recode(f.seqs[s], f.lengths[s]);
-        fwrite(f.seqs[s], 1, f.lengths[s], fs);
+    {   /* gather the sorted, recoded residues and write them in large blocks */
+        const size_t blk = (size_t)64 << 20;
+        char *out = (char *)malloc(blk);
+        if (!out) { fclose(fs); free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); }
+        size_t fill = 0;
+        for (uint64_t i = 0; i < f.count; ++i) {
+            uint64_t s = order[i];
+            size_t L = f.lengths[s], done = 0;
+            while (done < L) {
+                size_t n = L - done < blk - fill ? L - done : blk - fill;
+                memcpy(out + fill, f.seqs[s] + done, n);
+                fill += n; done += n;
+                if (fill == blk) { swimm_recode(out, fill); fwrite(out, 1, fill, fs); fill = 0; }
+            }
+        }
+        if (fill) { swimm_recode(out, fill); fwrite(out, 1, fill, fs); }
+        free(out);
     }
     int werr = ferror(fs);
     fclose(fs);

@@ -62,15 +62,18 @@ struct LaneItem {
 struct LaneParams {
     const LaneItem *items;
     uint32_t n_items;
-    uint32_t *queue;            // work cursor, zeroed before every launch
+    uint32_t *queue;            // [passes] work cursors, zeroed before the launch
+    uint32_t *prog;             // [passes][n_items] boundary columns published so far (global column + 1), zeroed
     const int16_t *prof;
     uint32_t prof_stride;
-    uint32_t r0;                // first query row of this pass
-    uint32_t rows;              // real query rows in this pass (<= 64 * kLaneRows)
-    uint2 *bnd;
-    int first_pass, last_pass;
+    uint32_t m;                 // query rows
+    uint32_t passes;            // ceil(m / (64 * kLaneRows)); all passes run in ONE launch, chained per item
+    uint32_t wg_per_pass;       // grid = passes * wg_per_pass workgroups, pass-major
+    unsigned long long *bnd[2]; // boundary rows (H | F << 32 per column): pass p writes bnd[p & 1], reads bnd[(p - 1) & 1]
+    uint32_t bnd_dummy;         // first index of a 64-entry dump area behind the real columns
     int32_t *out;
     int goe, ge;
+    uint32_t *err;              // watchdog word
 };
 size_t lane_lds_bytes();
 hipError_t launch_lane(Mode mode, int n_wg, const LaneParams &p, hipStream_t s);

@@ -468,8 +468,18 @@ struct LaneFeed {
     uint32_t flags[kChunkCols];
 };
 
+// Passes of a long query (512 rows each) are CHAINED inside one launch: the workgroups of pass p take the
+// items in the same order as those of pass p-1 and follow them through global memory.  The wave that runs
+// (item, p) publishes, per column, the bottom row of its last lane into bnd[p & 1] with agent-scope stores
+// and, two chunks later (s_waitcnt vmcnt(8): the youngest 8 operations are at least the last two chunks'
+// four stores each, so everything before them has completed), a per-item progress counter; the wave that runs (item, p+1) polls
+// that counter before it feeds the columns to its lane 0.  A 5 478-row query against a 35 000-residue
+// sequence is then 11 waves a few hundred columns apart instead of 11 launches one after the other.
+// No deadlock: the grid never exceeds one workgroup per CU (so all of it becomes resident), blocks are
+// pass-major (producers are dispatched first), every pass consumes the items in the same order and pass 0
+// never waits; all spins are bounded and report through p.err.
 template <bool PK>
-__global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
+__global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
 {
     typedef typename std::conditional<PK, OpsPK, OpsI32>::type Ops;
     typedef typename Ops::V V;
@@ -477,18 +487,27 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int PS = prof_row_bytes(RP);
+    const uint32_t pass = blockIdx.x / p.wg_per_pass;
+    const uint32_t r0 = pass * RP;
+    const uint32_t rows = p.m - r0 < (uint32_t)RP ? p.m - r0 : (uint32_t)RP;
+    const bool first_pass = pass == 0, last_pass = pass + 1 == p.passes;
+    uint32_t *const queue = p.queue + pass;
+    const uint32_t *const prog_in = p.prog + (first_pass ? 0 : (size_t)(pass - 1) * p.n_items);   // only read when pass > 0
+    uint32_t *const prog_out = p.prog + (size_t)pass * p.n_items;
+    const unsigned long long *const bnd_in = p.bnd[(pass + 1) & 1];
+    unsigned long long *const bnd_out = p.bnd[pass & 1];
     {
         const int dw_per_code = RP >> 1;
         for (int idx = threadIdx.x; idx < kCodes * dw_per_code; idx += blockDim.x) {
             const int d = idx / dw_per_code, x = idx - d * dw_per_code;
-            const uint32_t *src = (const uint32_t *)(p.prof + (size_t)d * p.prof_stride + p.r0);
+            const uint32_t *src = (const uint32_t *)(p.prof + (size_t)d * p.prof_stride + r0);
             *(uint32_t *)(smem + d * PS + x * 4) = src[x];
         }
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(2);   // these waves are long serial chains: let them issue ahead of bulk waves on the same SIMD
     const unsigned char *my_prof = smem + lane * TR * 2;
-    const int last_lane = (int)((p.rows + TR - 1) / TR) - 1;      // lane holding the query's last rows in this pass
+    const int last_lane = (int)((rows + TR - 1) / TR) - 1;      // lane holding the query's last rows in this pass
     const V goe = Ops::splat(p.goe), ge = Ops::splat(p.ge);
 
     V H[TR], E[TR];
@@ -503,23 +522,25 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
     uint32_t oH = 0, oF = 0, oT = 0, oS = 0, oC = 0;
     uint2 pb = make_uint2(0u, 0u);           // boundary-side values of the column lane 0 fed one step ago
     uint32_t pitem = 0, pcol = 0;
+    // progress publication (meaningful in the last lane): last real column of the previous chunk / the one before
 
     // producer state (wave-uniform): next chunk to feed
-    bool feeding = true;
-    uint32_t cc = 0, nch = 0, it_lane = 0, it_half = 0, it_bnd = 0, it_idx = 0;
+    bool feeding = true, dead = false;
+    uint32_t cc = 0, nch = 0, it_lane = 0, it_half = 0, it_bnd = 0, it_idx = 0, seen = 0;
     const uint8_t *it_db = nullptr;
     int drained = 0;
 
     auto produce = [&](LaneFeed &f) -> bool {   // false: nothing left and the pipeline has drained
         if (feeding && cc == nch) {
             uint32_t idx = 0;
-            if (lane == 0) idx = atomicAdd(p.queue, 1u);
+            if (lane == 0) idx = atomicAdd(queue, 1u);
             idx = __builtin_amdgcn_readfirstlane(idx);
             if (idx >= p.n_items) {
                 feeding = false;
             } else {
                 const LaneItem iv = p.items[idx];
                 it_idx = idx; cc = 0; nch = iv.ncols / C; it_db = iv.db; it_lane = iv.lane; it_half = iv.half; it_bnd = iv.bnd_off;
+                seen = 0;
             }
         }
 #pragma unroll
@@ -533,9 +554,23 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
             f.wa = (uint32_t)w;
             f.wb = (uint32_t)(w >> 32);
             f.col0 = it_bnd + cc * C;
-            if (!p.first_pass) {
+            if (!first_pass) {
+                const uint32_t need = f.col0 + C;            // the previous pass must have published these columns
+                if (seen < need) {
+                    uint32_t spins = 0;
+                    for (;;) {
+                        seen = __hip_atomic_load(prog_in + it_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen >= need) break;
+                        if (++spins > (1u << 24)) { dead = true; break; }
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                    if (dead) { if (lane == 0) atomicOr(p.err, 4u); feeding = false; return false; }
+                }
 #pragma unroll
-                for (int jj = 0; jj < C; ++jj) f.b[jj] = p.bnd[(size_t)f.col0 + jj];
+                for (int jj = 0; jj < C; ++jj) {
+                    const unsigned long long v = __hip_atomic_load(bnd_in + (size_t)f.col0 + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    f.b[jj] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+                }
             }
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) f.flags[jj] = kFlagReal;
@@ -548,12 +583,28 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
         return drained <= 64 + 2 * C;   // the last real column needs 1 + 63 more steps to leave lane 63
     };
 
+    // wave-uniform history of the chunks fed (bit i = the chunk fed i iterations ago): lane 63 computes, chunk
+    // aligned, the chunk that was fed 16 iterations earlier
+    uint32_t hist_real = 0, hist_first = 0, hist_end = 0;
     LaneFeed nxt;
     bool more = produce(nxt);
     while (more) {
-        LaneFeed cur = nxt;
+        // the feed is wave-uniform: keep the chunk being computed in scalar registers (the loads above land in
+        // vector registers), so that only the chunk in flight costs VGPRs
+        LaneFeed cur;
+        cur.wa = __builtin_amdgcn_readfirstlane(nxt.wa); cur.wb = __builtin_amdgcn_readfirstlane(nxt.wb);
+#pragma unroll
+        for (int jj = 0; jj < C; ++jj) {
+            cur.b[jj].x = __builtin_amdgcn_readfirstlane(nxt.b[jj].x); cur.b[jj].y = __builtin_amdgcn_readfirstlane(nxt.b[jj].y);
+            cur.flags[jj] = __builtin_amdgcn_readfirstlane(nxt.flags[jj]);
+        }
+        cur.item = __builtin_amdgcn_readfirstlane(nxt.item); cur.col0 = __builtin_amdgcn_readfirstlane(nxt.col0);
+        cur.half = __builtin_amdgcn_readfirstlane(nxt.half);
         more = produce(nxt);         // loads of the next chunk are in flight while this one is computed
         if (!PK && cur.half) cur.wa = cur.wb;
+        hist_real = (hist_real << 1) | ((cur.flags[0] & kFlagReal) ? 1u : 0u);
+        hist_first = (hist_first << 1) | ((cur.flags[0] & kFlagStart) ? 1u : 0u);
+        hist_end = (hist_end << 1) | ((cur.flags[C - 1] & kFlagEnd) ? 1u : 0u);
 #pragma unroll
         for (int jj = 0; jj < C; ++jj) {
             uint32_t d0 = ((cur.wa >> (8 * jj)) & 0xffu) | cur.flags[jj];
@@ -592,22 +643,37 @@ __global__ void __launch_bounds__(256) sw_lane_kernel(const LaneParams p)
             }
             oH = Ops::bits(H[TR - 1]); oF = Ops::bits(F); oS = Sin; oC = Cin; oT = Tin;
             if (D & kFlagEnd) oT = Ops::bits(Ops::vmax(Ops::from_bits(Tin), best));   // running best of the alignment
-            if (lane == last_lane && (D & kFlagReal)) {   // fill / drain columns must never reach memory
-                if (!p.last_pass) p.bnd[Cin] = make_uint2(oH, oF);
-                if (D & kFlagEnd) {
-                    const LaneItem *iv = p.items + Sin;
-                    if (PK) {
-                        const v2s b2 = __builtin_bit_cast(v2s, oT);
-                        atomicMax(p.out + iv->slot_a, (int)b2.x);
-                        atomicMax(p.out + iv->slot_b, (int)b2.y);
-                    } else {
-                        atomicMax(p.out + iv->slot_a, (int)oT);
-                    }
+            const bool mine = lane == last_lane && (D & kFlagReal);   // fill / drain columns must never reach real memory
+            if (!last_pass && mine)   // one lane, four stores per real chunk (lane 63's chunks are chunk aligned)
+                __hip_atomic_store(bnd_out + Cin, ((unsigned long long)oF << 32) | oH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine && (D & kFlagEnd)) {   // every pass contributes the best of its own rows
+                const LaneItem *iv = p.items + Sin;
+                if (PK) {
+                    const v2s b2 = __builtin_bit_cast(v2s, oT);
+                    atomicMax(p.out + iv->slot_a, (int)b2.x);
+                    atomicMax(p.out + iv->slot_b, (int)b2.y);
+                } else {
+                    atomicMax(p.out + iv->slot_a, (int)oT);
                 }
             }
             // advance both streams
             oDn = Dn; Dcur = Dn; acur = an; bcur = bn;
             pb = cur.b[jj]; pitem = cur.item; pcol = cur.col0 + jj;
+        }
+        if (!last_pass && ((hist_real >> 16) & 1u)) {
+            // Lane 63 has just stored the boundary of the chunk fed 16 iterations ago, which ends at column oC.
+            // Vector-memory operations complete in issue order; the youngest 8 are at least this chunk's and the
+            // previous chunk's 4 stores, so after vmcnt(8) the chunk two back (ending at oC - 8, same item unless
+            // this is the item's first or second chunk) is in memory and may be published.  An item's last chunk is
+            // published at once behind a full wait.
+            if ((hist_end >> 16) & 1u) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 63) __hip_atomic_store(prog_out + oS, oC + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (lane == 63 && !((hist_first >> 16) & 3u))
+                    __hip_atomic_store(prog_out + oS, oC + 1 - 2 * C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }

@@ -88,6 +88,13 @@ struct DbPlan {          // per (mode, n_wg): main partition + the groups handed
     LaneList tail;
 };
 
+// scratch of one lane-kernel stream: boundary rows of even / odd passes, per-pass queues, progress counters
+struct LaneScratch {
+    DevBuf<unsigned long long> bnd[2];
+    DevBuf<uint32_t> queue, prog;
+    void release() { bnd[0].release(); bnd[1].release(); queue.release(); prog.release(); }
+};
+
 struct ChunkRec {
     uint8_t *d_tiled = nullptr;
     uint64_t first_seq = 0;     // global sorted index of the chunk's first sequence
@@ -136,11 +143,10 @@ struct swimm_hip_ctx {
     DevBuf<int64_t> d_gbase;
     DevBuf<uint32_t> d_gvalid;
     DevBuf<unsigned long long> d_keys;
-    DevBuf<uint32_t> d_queue;
     DevBuf<uint32_t> d_err;             // pipeline watchdog word
     DevBuf<unsigned long long> d_stamps;   // diagnostic build only
-    DevBuf<uint2> d_bnd2;               // pass boundary of the lane kernel (its own stream)
-    DevBuf<uint2> d_bnd3;               // ... of the promotion re-runs (third stream)
+    LaneScratch tail_scratch;           // lane kernel on stream 2 (long-sequence tail)
+    LaneScratch rerun_scratch;          // lane kernel on stream 3 (promotion re-runs)
     DevBuf<LaneItem> d_rerun_items;
     DevBuf<uint32_t> d_satlist;
     // stats of the last search
@@ -390,36 +396,54 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
     return 0;
 }
 
-// all passes of the lane-systolic kernel over one work list for one query
+// the lane-systolic kernel over one work list for one query: ONE launch, all passes chained per item
 int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row, hipStream_t st,
-                    DevBuf<uint2> &bnd, uint32_t *queue_word)
+                    LaneScratch &sc)
 {
     if (ll.n == 0) return 0;
     const int rows_pass = 64 * kLaneRows;
     const int passes = (m + rows_pass - 1) / rows_pass;
-    if (passes > 1 && bnd.cap < ll.cols) return fail("internal: lane boundary buffer too small (%zu < %llu)", bnd.cap, (unsigned long long)ll.cols);
-    // 4 waves per workgroup; enough workgroups to fill the chip (58 VGPRs: 8 waves/SIMD, 26 KB LDS: 6 per CU)
-    const int n_wg = (int)std::max<uint64_t>(1, std::min<uint64_t>((ll.n + 3) / 4, (uint64_t)c->num_cu * 6));
-    for (int pass = 0; pass < passes; ++pass) {
-        LaneParams p{};
-        p.items = ll.items.p;
-        p.n_items = ll.n;
-        p.queue = queue_word;
-        p.prof = c->d_prof.p + qp.prof_off;
-        p.prof_stride = qp.mpad;
-        p.r0 = (uint32_t)(pass * rows_pass);
-        p.rows = (uint32_t)std::min(rows_pass, m - pass * rows_pass);
-        p.bnd = bnd.p;
-        p.first_pass = pass == 0;
-        p.last_pass = pass == passes - 1;
-        p.out = out_row;
-        p.goe = c->open_gap + c->extend_gap;
-        p.ge = c->extend_gap;
-        HIP_TRY(hipMemsetAsync(queue_word, 0, sizeof(uint32_t), st));
-        HIP_TRY(launch_lane(mode, n_wg, p, st));
-        c->launches++;
-        c->cells += ll.cell_cols * (uint64_t)rows_pass * (mode == Mode::PK16 ? 2 : 1);
+    const size_t need_bnd = passes > 1 ? (size_t)ll.cols + 64 : 0, need_prog = (size_t)passes * ll.n;
+    if (sc.bnd[0].cap < need_bnd || sc.bnd[1].cap < need_bnd || sc.queue.cap < (size_t)passes || sc.prog.cap < need_prog)
+        return fail("internal: lane scratch too small (%zu/%zu columns, %zu/%zu counters)", sc.bnd[0].cap, need_bnd, sc.prog.cap, need_prog);
+    // never more than one workgroup per CU in total: the whole grid becomes resident (a pass waits for the one
+    // before it), pass-major so that producers are dispatched first; 4 waves per workgroup
+    int per_pass = passes > 1 ? std::max(1, c->num_cu / passes) : c->num_cu * 6;   // a single pass chains nothing: fill the chip
+    per_pass = (int)std::min<uint64_t>(per_pass, (ll.n + 3) / 4);
+    if (passes > c->num_cu) return fail("query of %d rows needs %d chained passes, more than the %d CUs", m, passes, c->num_cu);
+    LaneParams p{};
+    p.items = ll.items.p;
+    p.n_items = ll.n;
+    p.queue = sc.queue.p;
+    p.prog = sc.prog.p;
+    p.prof = c->d_prof.p + qp.prof_off;
+    p.prof_stride = qp.mpad;
+    p.m = (uint32_t)m;
+    p.passes = (uint32_t)passes;
+    p.wg_per_pass = (uint32_t)per_pass;
+    p.bnd[0] = sc.bnd[0].p;
+    p.bnd[1] = sc.bnd[1].p;
+    p.bnd_dummy = (uint32_t)ll.cols;
+    p.out = out_row;
+    p.goe = c->open_gap + c->extend_gap;
+    p.ge = c->extend_gap;
+    p.err = c->d_err.p;
+    HIP_TRY(hipMemsetAsync(sc.queue.p, 0, passes * sizeof(uint32_t), st));
+    if (passes > 1) HIP_TRY(hipMemsetAsync(sc.prog.p, 0, need_prog * sizeof(uint32_t), st));
+    HIP_TRY(launch_lane(mode, passes * per_pass, p, st));
+    c->launches++;
+    c->cells += ll.cell_cols * (uint64_t)rows_pass * passes * (mode == Mode::PK16 ? 2 : 1);
+    return 0;
+}
+
+int reserve_lane_scratch(LaneScratch &sc, size_t cols, size_t items, int passes)
+{
+    HIP_TRY(sc.queue.reserve(256));
+    if (passes > 1) {
+        HIP_TRY(sc.bnd[0].reserve(cols + 64));
+        HIP_TRY(sc.bnd[1].reserve(cols + 64));
     }
+    HIP_TRY(sc.prog.reserve(std::max<size_t>(1, items * (size_t)passes)));
     return 0;
 }
 
@@ -484,23 +508,26 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     HIP_TRY(hipMemsetAsync(c->d_scores.p, 0, (size_t)qn * S * sizeof(int32_t), c->stream));
 
     // buffers that later launches grow are sized up front: a reallocation in the middle of the
-    // two-stream phase would free memory a kernel in flight still uses
+    // multi-stream phase would free memory a kernel in flight still uses
     {
-        uint64_t need_bnd = 0, need_bnd2 = 0;
+        uint64_t need_bnd = 0;
+        size_t tail_cols = 0, tail_items = 0;
+        int max_passes = 1;
         for (uint32_t q = 0; q < qn; ++q) {
             int per_cu = 1;
             if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
             DbPlan *dp = nullptr;
             if (get_db_plan(c, main_mode, c->num_cu * per_cu, &dp)) return 1;
             if (qps[q].passes > 1 && dp->have_main) need_bnd = std::max<uint64_t>(need_bnd, dp->main.bnd_cols * 64);
-            if (c->qm[q] > 64 * kLaneRows) need_bnd2 = std::max<uint64_t>(need_bnd2, dp->tail.cols);
+            tail_cols = std::max<size_t>(tail_cols, dp->tail.cols);
+            tail_items = std::max<size_t>(tail_items, dp->tail.n);
+            max_passes = std::max(max_passes, (int)((c->qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
         }
         HIP_TRY(c->d_bnd.reserve(need_bnd));
-        HIP_TRY(c->d_bnd2.reserve(need_bnd2));
-        HIP_TRY(c->d_queue.reserve(2));                      // [0] tail stream, [1] promotion stream
+        if (reserve_lane_scratch(c->tail_scratch, tail_cols, tail_items, max_passes)) return 1;
+        if (reserve_lane_scratch(c->rerun_scratch, (size_t)1 << 22, 4096, max_passes)) return 1;
         HIP_TRY(c->d_satlist.reserve((size_t)(1u << 16) + 1));
         HIP_TRY(c->d_rerun_items.reserve(4096));
-        HIP_TRY(c->d_bnd3.reserve((size_t)1 << 22));
     }
     HIP_TRY(c->d_err.reserve(1));
     HIP_TRY(hipMemsetAsync(c->d_err.p, 0, sizeof(uint32_t), c->stream));
@@ -526,7 +553,7 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             fprintf(stderr, "swimm_hip: query %u: %d workgroups (%d per CU), %u tail items, main %s\n", q, dp->main.n_wg, per_cu, dp->tail.n, dp->have_main ? "yes" : "no");
         // the long-sequence tail (a few long serial chains, one wave each) runs on its own stream beside the
         // bulk kernel: 3 bulk waves (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly
-        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row, c->stream2, c->d_bnd2, c->d_queue.p)) return 1;
+        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row, c->stream2, c->tail_scratch)) return 1;
         if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row)) return 1;
         HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
         HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->stream2));
@@ -559,18 +586,20 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             std::stable_sort(items.begin(), items.end(), [](const LaneItem &a, const LaneItem &b) { return a.ncols > b.ncols; });
             uint64_t cols = 0;
             for (LaneItem &it : items) { it.bnd_off = (uint32_t)cols; cols += it.ncols; }
-            if (items.size() > c->d_rerun_items.cap || cols > c->d_bnd3.cap) {
+            const int rpasses = (int)((c->qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows));
+            if (items.size() > c->d_rerun_items.cap || (rpasses > 1 && cols + 64 > c->rerun_scratch.bnd[0].cap) ||
+                items.size() * (size_t)rpasses > c->rerun_scratch.prog.cap) {
                 // growing a buffer frees the old one, which waits for the whole device: rare (first big batch)
                 HIP_TRY(hipDeviceSynchronize());
                 HIP_TRY(c->d_rerun_items.reserve(items.size() * 2));
-                HIP_TRY(c->d_bnd3.reserve(cols * 2));
+                if (reserve_lane_scratch(c->rerun_scratch, cols * 2, items.size() * 2, rpasses)) return 1;
             }
             HIP_TRY(hipMemcpyAsync(c->d_rerun_items.p, items.data(), items.size() * sizeof(LaneItem), hipMemcpyHostToDevice, c->stream3));
             HIP_TRY(hipStreamSynchronize(c->stream3));       // `items` is a host temporary
             LaneList ll;
             ll.items.p = c->d_rerun_items.p; ll.items.cap = c->d_rerun_items.cap;
             ll.n = (uint32_t)items.size(); ll.cols = cols; ll.cell_cols = cols;
-            const int rc = run_lane_passes(c, mode, qps[q], c->qm[q], ll, c->d_scores.p + (size_t)q * S, c->stream3, c->d_bnd3, c->d_queue.p + 1);
+            const int rc = run_lane_passes(c, mode, qps[q], c->qm[q], ll, c->d_scores.p + (size_t)q * S, c->stream3, c->rerun_scratch);
             ll.items.p = nullptr; ll.items.cap = 0;           // borrowed
             return rc;
         };
@@ -680,7 +709,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
     c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
-    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_queue.release(); c->d_err.release(); c->d_bnd2.release(); c->d_bnd3.release(); c->d_rerun_items.release(); c->d_satlist.release();
+    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);

@@ -170,7 +170,8 @@ int regs_to_waves_per_simd(int regs)
     return std::max(1, std::min(8, 512 / std::max(alloc, 8)));
 }
 
-// T rows per wave, W waves per workgroup, number of passes for a query of m rows
+// how many workgroups of W waves of the T-row kernel one CU holds (VGPRs: 8-register granule, 512 per SIMD
+// lane; LDS: 160 KiB)
 int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
 {
     int regs = 0;

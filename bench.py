@@ -244,7 +244,7 @@ def main():
                        "topr_exchange": "none" if world == 1 else ("rccl all_gather" if rccl is not None else "gloo all_gather")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "sw_pipe_kernel<T, packed f16>", "kernel_ms": round(k_ms / launches, 4),
+                         "kernel": f"swimm::sw_pipe_kernel<{T}, 2, false>", "kernel_ms": round(k_ms / launches, 4),
                          "alg_bytes_per_launch": alg_bytes,
                          "note": "VALU-bound kernel: see valu_roofline; HBM carries only the DB residues (1/m B per cell)"},
             "valu_roofline": {"achieved": round(ginstr, 1), "peak": round(VALU_PEAK_GINSTR, 1), "unit": "G wave-instr/s",

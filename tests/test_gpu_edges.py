@@ -91,3 +91,15 @@ def test_scores_on_the_promotion_thresholds(opts):
     for t in targets:
         assert (want == t).any(), t            # every threshold value really occurs
     assert stats["promoted"] >= 2              # 32767 and 32768 needed the int32 tier
+
+
+def test_chained_lane_passes_many_items():
+    """every group through the lane-systolic kernel with 3 and 6 chained passes and thousands of items in
+    flight: the inter-wave hand-over (boundary rows + progress counters through global memory) under load"""
+    rng = np.random.default_rng(21)
+    q1, q2 = rnd(rng, 1500), rnd(rng, 2900)
+    seqs = [rnd(rng, int(n)) for n in rng.integers(1, 900, 2500)]
+    seqs += [np.concatenate([rnd(rng, 40), q1[200:1300], rnd(rng, 15)]), np.concatenate([q2[:2000], rnd(rng, 300)])]
+    for opts in ({"tail_mode": 1}, {"tail_mode": 1, "f16": 0}):
+        want, stats = run_case(seqs, [q1, q2], matrix="blosum50", opts=opts, max_chunk=200000)
+        assert want.max() > 2048

@@ -189,7 +189,7 @@ int main(int argc, char **argv)
     } else {
         printf("Execution mode:\t\t\tMI355X only (%d GPUs)\n", o.num_gpus);
         printf("Profile technique:\t\tQuery Profile in LDS\n");
-        printf("Instruction set:\t\tgfx950 packed int16, int32 promotion (vector length = 128)\n");
+        printf("Instruction set:\t\tgfx950 packed binary16 -> int16 -> int32 ladder (vector length = 128)\n");
         printf("Max. chunk size:\t\t%ld bytes\n", o.max_chunk_size);
         printf("Chunk count:\t\t\t%ld \n", (long)chunk_count);
         printf("Kernel time:\t\t\t%lf seconds\n", kernel_ms / 1000.0);

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (written by tools/profile_bench.sh) into the files under profiles/.
+
+usage: python tools/summarize_profile.py <tag> [round-prefix, default r01]
+  profiles/<rnd>_c2_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied)
+  profiles/<rnd>_c2_pmc_summary.csv    per-counter mean per launch of the dominant kernel
+  profiles/<rnd>_pmc_traffic.json      HBM bytes per launch with the gfx950 corrections
+                                       (MI355X_MICROARCH.md: FETCH_SIZE x2 on streaming reads, KB units)
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find(base, pat):
+    hits = glob.glob(os.path.join(base, "**", pat), recursive=True)
+    return sorted(hits)
+
+
+def main():
+    tag = sys.argv[1]
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+    base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    out = os.path.join(ROOT, "profiles")
+
+    stats = find(os.path.join(base, "kt"), "*kernel_stats.csv")
+    if not stats:
+        sys.exit(f"no kernel_stats.csv under {base}/kt")
+    rows = list(csv.DictReader(open(stats[0])))
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    dominant = rows[0]["Name"]
+    with open(os.path.join(out, f"{rnd}_c2_kernel_stats.csv"), "w") as f:
+        f.write(open(stats[0]).read())
+
+    per = defaultdict(lambda: defaultdict(float))   # counter -> dispatch id -> value (summed over XCD rows)
+    dispatch = None
+    for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
+        for fn in find(os.path.join(base, p), "*counter_collection.csv"):
+            for r in csv.DictReader(open(fn)):
+                if r["Kernel_Name"] != dominant:
+                    continue
+                per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+                if dispatch is None:
+                    dispatch = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                                  "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Kernel_Name") if k in r}
+    with open(os.path.join(out, f"{rnd}_c2_pmc_summary.csv"), "w") as f:
+        f.write(f"# rocprofv3 --pmc passes (tools/profile_bench.sh {tag}), bench.py c2 full scale, default path\n")
+        f.write(f"# dispatch: {json.dumps(dispatch)}\n")
+        f.write("counter,launches,mean_per_launch\n")
+        for c in sorted(per):
+            v = list(per[c].values())
+            f.write(f"{c},{len(v)},{sum(v) / len(v)}\n")
+
+    def mean(c):
+        v = list(per[c].values())
+        return sum(v) / len(v) if v else None
+
+    fetch, write = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+    if fetch is not None and write is not None:
+        traffic = {
+            "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE, separate passes (profiles/{rnd}_c2_pmc_summary.csv)",
+            "kernel": dominant,
+            "workload": "bench.py c2, 1M sequences, 375-aa query",
+            "FETCH_SIZE_KB": fetch,
+            "WRITE_SIZE_KB": write,
+            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on coalesced streaming reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
+            "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+            "grbm_gui_active_sum_over_8_xcd": mean("GRBM_GUI_ACTIVE"),
+        }
+        json.dump(traffic, open(os.path.join(out, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
+    print("dominant kernel:", dominant)
+    print("avg ns:", rows[0]["AverageNs"], "calls:", rows[0]["Calls"])
+    for c in sorted(per):
+        print(f"  {c}: {mean(c):.1f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -142,6 +142,10 @@ def main():
             except Exception as e:   # result path only: fall back to gloo, say so in the output
                 print(f"[rank {rank}] RCCL group unavailable ({e}); top-r lists go over gloo", file=sys.stderr)
                 rccl = None
+            ok = torch.tensor([1 if rccl is not None else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank takes the same result path
+            if int(ok.item()) == 0:
+                rccl = None
 
     sm = submat.table("blosum62")
     shard = build_shard(2 + 1000 * rank, args.scale)

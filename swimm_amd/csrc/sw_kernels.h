@@ -79,6 +79,8 @@ size_t lane_lds_bytes();
 hipError_t launch_lane(Mode mode, int n_wg, const LaneParams &p, hipStream_t s);
 
 size_t pipe_lds_bytes(int rows_per_wave, int waves, bool flag_sync);
+// which (tier, rows per wave, hand-over scheme) kernels exist
+bool pipe_has_variant(Mode mode, int rows_per_wave, bool flag_sync);
 // registers / occupancy of one instantiation (for the host-side launch plan)
 hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, int *num_regs);
 hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, bool flag_sync, int n_wg, const PipeParams &p, hipStream_t s);

@@ -155,9 +155,11 @@ __host__ __device__ constexpr int prof_row_bytes(int rows) { return rows * 2 + 1
 // ring slots per wave: 2 with one workgroup barrier per chunk, kFlagRing when neighbouring waves hand
 // chunks over through LDS counters and may drift apart by that many chunks
 constexpr int kFlagRing = 4;
+// a wave's strip of T rows occupies round8(T) rows of the LDS profile, so that its ds_read_b128 stay 16-byte aligned
+__host__ __device__ constexpr int strip_lds_rows(int T) { return (T + 7) & ~7; }
 size_t pipe_lds_bytes(int T, int W, bool flag_sync)
 {
-    return round16((size_t)kCodes * prof_row_bytes(T * W)) + (size_t)W * (flag_sync ? kFlagRing : 2) * kChunkCols * 64 * sizeof(uint2) + 128;
+    return round16((size_t)kCodes * prof_row_bytes(strip_lds_rows(T) * W)) + (size_t)W * (flag_sync ? kFlagRing : 2) * kChunkCols * 64 * sizeof(uint2) + 128;
 }
 
 // bounded wait on an LDS counter another wave of the same workgroup advances (all waves of a workgroup are
@@ -178,8 +180,10 @@ __device__ __forceinline__ bool wait_counter_above(const uint32_t *ctr, uint32_t
 //     9 700 / 14 100 cycles); letting the early waves run ahead through counters did NOT help (A/B in one
 //     process: 32.06 vs 31.55 ms on c2): the VALU is already kept as busy as three waves can keep it.
 template <int T, int M, bool FS>
-__global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
+__global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
 {
+    static_assert(T % 4 == 0 && T >= 8, "strips are multiples of 4 rows");
+    constexpr int TP = strip_lds_rows(T);
     constexpr bool PK = M != 1;
     constexpr int R = FS ? kFlagRing : 2;
     typedef typename std::conditional<M == 0, OpsPK, typename std::conditional<M == 1, OpsI32, OpsF16>::type>::type Ops;
@@ -190,7 +194,7 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
     const int W = blockDim.x >> 6;
     const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index = query strip
     const int lane = threadIdx.x & 63;
-    const int RW = W * T;
+    const int RW = W * TP;
     const int PS = prof_row_bytes(RW);
     unsigned char *prof_lds = smem;
     uint2 *ring = (uint2 *)(smem + round16((size_t)kCodes * PS));
@@ -198,13 +202,19 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
     uint32_t *cons = prod + 16;                                     // cons[k]: chunks wave k has taken from wave k-1
     if (threadIdx.x < 32) prod[threadIdx.x] = 0;
 
-    // stage this pass's window of the query profile: rows [r0, r0 + W*T) of all 25 codes
+    // stage this pass's window of the query profile: rows [r0, r0 + W*T) of all 25 codes, strip k at LDS row k*TP
     {
         const int dw_per_code = RW >> 1;
         for (int idx = threadIdx.x; idx < kCodes * dw_per_code; idx += blockDim.x) {
             const int d = idx / dw_per_code, x = idx - d * dw_per_code;
             const uint32_t *src = (const uint32_t *)(p.prof + (size_t)d * p.prof_stride + p.r0);
-            uint32_t v = src[x];
+            int sx = x;
+            if (TP != T) {
+                const int strip = (2 * x) / TP, r = 2 * x - strip * TP;
+                if (r >= T) continue;                // alignment rows, never read
+                sx = (strip * T + r) >> 1;
+            }
+            uint32_t v = src[sx];
             if (M == 2) {                           // int16 scores -> binary16
                 const v2s sv = as_v2s(v);
                 v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)sv.x, (_Float16)(float)sv.y});
@@ -219,7 +229,7 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
     uint32_t it = p.wg_first[blockIdx.x];
     const int total = (int)p.wg_chunks[blockIdx.x];
     const int nsteps = FS ? total : total + W - 1;
-    const unsigned char *my_prof = prof_lds + k * T * 2;
+    const unsigned char *my_prof = prof_lds + k * TP * 2;
 
     V H[T], E[T];
     V best = Ops::zero(), diag_top = Ops::zero();
@@ -341,6 +351,29 @@ __global__ void __launch_bounds__(T >= 32 ? 768 : 1024) sw_pipe_kernel(const Pip
                         }
                     }
                 }
+                if (T % 8 == 4) {                    // last 4 rows of the strip: one ds_read_b64 per residue
+                    constexpr int rb = T - 4;
+                    const uint2 a = *(const uint2 *)(pa + rb * 2);
+                    const uint32_t aw[2] = {a.x, a.y};
+                    if (PK) {
+                        const uint2 b = *(const uint2 *)(pb + rb * 2);
+                        const uint32_t bw[2] = {b.x, b.y};
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int r = rb + q * 2;
+                            cell2<Ops>(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
+                                       Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
+                                       Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int r = rb + q * 2;
+                            cell2<Ops>(hd, H[r], E[r], H[r + 1], E[r + 1], F, best, Ops::from_bits((uint32_t)(int)(short)(aw[q] & 0xffffu)),
+                                       Ops::from_bits((uint32_t)((int)aw[q] >> 16)), goe, ge);
+                        }
+                    }
+                }
                 // bottom boundary of this column: to the next wave through LDS, or (last wave, more passes) to HBM
                 const uint2 bout = make_uint2(Ops::bits(H[T - 1]), Ops::bits(F));
                 if (k < W - 1) ring[(size_t)((k * R + (c & (R - 1))) * C + jj) * 64 + lane] = bout;
@@ -403,9 +436,24 @@ static hipError_t launch_mode(Mode mode, int W, int n_wg, const PipeParams &p, h
     return launch_one<T, 2, FS>(W, n_wg, p, s);
 }
 
+// Instantiations: T = 16 / 24 / 32 for every tier and both hand-over schemes; the f16 tier with barriers (the
+// default path) also has every other multiple of 4 from 8 to 36, so that the launch plan can give a query
+// W = 4, 8, 12 or 16 waves (an equal number on each of the CU's 4 SIMDs) with at most 3 padding rows per wave.
+#define SWIMM_EXTRA_T(X) X(8) X(12) X(20) X(28) X(36)
+bool pipe_has_variant(Mode mode, int T, bool flag_sync)
+{
+    if (T == 16 || T == 24 || T == 32) return true;
+    if (mode != Mode::F16 || flag_sync) return false;
+#define X(t) if (T == t) return true;
+    SWIMM_EXTRA_T(X)
+#undef X
+    return false;
+}
+
 hipError_t launch_pipe(Mode mode, int T, int W, bool flag_sync, int n_wg, const PipeParams &p, hipStream_t s)
 {
-    if (W < 1 || W > kMaxWaves || n_wg < 1) return hipErrorInvalidValue;
+    if (W < 1 || W > kMaxWaves || n_wg < 1 || !pipe_has_variant(mode, T, flag_sync)) return hipErrorInvalidValue;
+    if (T > 28 && W > 12) return hipErrorInvalidValue;    // __launch_bounds__ of those instantiations
     if (flag_sync) {
         if (T == 32) return launch_mode<32, true>(mode, W, n_wg, p, s);
         if (T == 24) return launch_mode<24, true>(mode, W, n_wg, p, s);
@@ -414,6 +462,9 @@ hipError_t launch_pipe(Mode mode, int T, int W, bool flag_sync, int n_wg, const 
         if (T == 32) return launch_mode<32, false>(mode, W, n_wg, p, s);
         if (T == 24) return launch_mode<24, false>(mode, W, n_wg, p, s);
         if (T == 16) return launch_mode<16, false>(mode, W, n_wg, p, s);
+#define X(t) if (T == t) return launch_one<t, 2, false>(W, n_wg, p, s);
+        SWIMM_EXTRA_T(X)
+#undef X
     }
     return hipErrorInvalidValue;
 }
@@ -421,19 +472,22 @@ hipError_t launch_pipe(Mode mode, int T, int W, bool flag_sync, int n_wg, const 
 template <int T>
 static const void *kernel_ptr(Mode mode)
 {
-    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0, true>;
-    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1, true>;
-    return (const void *)sw_pipe_kernel<T, 2, true>;
+    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0, false>;
+    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1, false>;
+    return (const void *)sw_pipe_kernel<T, 2, false>;
 }
 
 hipError_t pipe_kernel_attributes(Mode mode, int T, int *num_regs)
 {
     hipFuncAttributes a;
     const void *f = nullptr;
+    if (!pipe_has_variant(mode, T, false)) return hipErrorInvalidValue;
     if (T == 32) f = kernel_ptr<32>(mode);
     else if (T == 24) f = kernel_ptr<24>(mode);
     else if (T == 16) f = kernel_ptr<16>(mode);
-    else return hipErrorInvalidValue;
+#define X(t) else if (T == t) f = (const void *)sw_pipe_kernel<t, 2, false>;
+    SWIMM_EXTRA_T(X)
+#undef X
     hipError_t e = hipFuncGetAttributes(&a, f);
     if (e == hipSuccess) *num_regs = a.numRegs;
     return e;

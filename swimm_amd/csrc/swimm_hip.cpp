@@ -116,7 +116,8 @@ struct swimm_hip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cu = 0;
     // options
-    int opt_T = 0, opt_maxW = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;   // 0 = chosen per query
+    int opt_T = 0, opt_maxW = 0, opt_W = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;   // 0 = chosen per query
+    int regs_cache[3][40] = {};            // VGPRs of sw_pipe_kernel<T, tier>, looked up once
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
     int opt_sync = 0;                   // 0: one barrier per chunk (default, measured faster); 1: counter hand-over between neighbouring waves
     int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
@@ -174,8 +175,8 @@ int regs_to_waves_per_simd(int regs)
 // lane; LDS: 160 KiB)
 int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
 {
-    int regs = 0;
-    HIP_TRY(pipe_kernel_attributes(mode, T, &regs));
+    int &regs = const_cast<swimm_hip_ctx *>(c)->regs_cache[(int)mode][T];
+    if (regs == 0) HIP_TRY(pipe_kernel_attributes(mode, T, &regs));
     const int waves_cu = 4 * regs_to_waves_per_simd(regs);
     const size_t lds = pipe_lds_bytes(T, W, c->opt_sync != 0);
     int n = std::min(waves_cu / W, (int)(163840 / lds));
@@ -184,39 +185,54 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
     return 0;
 }
 
-// measured issue interval of a half-rate VALU instruction (cycles) by waves per SIMD
-// (tools/microbench/valu_rate, profiles/r01_valu_issue_rates.txt)
-double issue_cycles(double waves_per_simd)
-{
-    static const double w[] = {1, 2, 3, 4, 6, 8}, cyc[] = {5.70, 4.71, 4.48, 4.40, 4.27, 4.22};
-    if (waves_per_simd <= 1) return cyc[0] / std::max(waves_per_simd, 0.25);   // a SIMD without a wave does nothing
-    for (int i = 1; i < 6; ++i)
-        if (waves_per_simd <= w[i]) return cyc[i - 1] + (cyc[i] - cyc[i - 1]) * (waves_per_simd - w[i - 1]) / (w[i] - w[i - 1]);
-    return cyc[5];
-}
+// Measured throughput (GCUPS of padded cells) of every launch shape of the f16-tier pipeline kernel: rows per wave
+// T = 8, 12, ... 36 (lines) by waves per workgroup W = 1..16 (columns), workgroups per CU by occupancy
+// (tools/plan_sweep.py on one MI355X, profiles/r01_plan_sweep.txt).  W = 4, 8, 12, 16 put the same number of waves
+// on each of the CU's 4 SIMDs; any other W runs like the next multiple of 4 (2 x 6 waves behave like 4+4+2+2).
+static const float kShapeGcups[8][16] = {
+    {2750, 5011, 5273, 5995, 5156, 5460, 5891, 6738, 5749, 4414, 5880, 6347, 5738, 5909, 5432, 6724},   // T=8
+    {3455, 5329, 5554, 6314, 5038, 5725, 6351, 7053, 5764, 5955, 6496, 7076, 5305, 5648, 6059, 6496},   // T=12
+    {3955, 5667, 5644, 6935, 5552, 4427, 6127, 6993, 4925, 5459, 6007, 6543, 5695, 6098, 6527, 6960},   // T=16
+    {4292, 5877, 5850, 7186, 4716, 5540, 6427, 7278, 5140, 5676, 6225, 6820, 5768, 6335, 6769, 7246},   // T=20
+    {4555, 6083, 5792, 7406, 4948, 5664, 6570, 7430, 5270, 5872, 6444, 7036, 5978, 6495, 6961, 7461},   // T=24
+    {4606, 6096, 5846, 7497, 5402, 5768, 6682, 7613, 5454, 6019, 6651, 7223, 6171, 6619, 7115, 7560},   // T=28
+    {4803, 6226, 5959, 7301, 4340, 5161, 6015, 6854, 5540, 6095, 6729, 7326, 0, 0, 0, 0},               // T=32
+    {4775, 6275, 5682, 7403, 4395, 5243, 5951, 6971, 5589, 6200, 6407, 7454, 0, 0, 0, 0},               // T=36
+};
 
-// Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the candidate with the
-// best modelled VALU efficiency = (real rows / padded rows) x (issue rate at the occupancy it reaches) x
-// (row instructions / (row + per-column instructions)).  Short queries gain up to 40 % over "always T=32"
-// (m=189: 6 waves of 32 rows -> 8 of 24, two workgroups per CU).
-int choose_plan(const swimm_hip_ctx *c, Mode mode, int m, int forced_T, QueryPlan *out)
+// Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the shape with the lowest
+// predicted time per database column, passes x (T x W padded rows) / measured rate of that shape; with more than
+// one pass the strip boundaries go through HBM and the first wave waits for its loads: measured 2.5 % for
+// W >= 8, 17 % for the 4-wave shapes (c5-shaped shard, queries of 464 ... 5478 rows).  `room_for_lane_waves`: the database has a long-sequence
+// tail that the lane kernel aligns on a second stream while this kernel runs; only shapes that leave the 80
+// VGPRs per SIMD lane a lane-systolic wave needs are admitted (e.g. 3 waves x 144, 4 x 104).
+int choose_plan(const swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, QueryPlan *out)
 {
-    double best_eff = -1;
-    for (int T : {32, 24, 16}) {
-        if (forced_T && T != forced_T) continue;
-        int maxW = (T == 32) ? 12 : 16;       // __launch_bounds__ of the instantiations
+    double best_cost = -1;
+    for (int ti = 7; ti >= 0; --ti) {
+        const int T = 8 + 4 * ti;
+        if (c->opt_T && T != c->opt_T) continue;
+        if (!pipe_has_variant(mode, T, c->opt_sync != 0)) continue;
+        int maxW = (T > 28) ? 12 : 16;        // __launch_bounds__ of the instantiations
         if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
         const int strips = std::max(1, (m + T - 1) / T);
-        const int passes = (strips + maxW - 1) / maxW;
-        const int W = (strips + passes - 1) / passes;
-        int per_cu = 1;
-        if (wgs_per_cu(c, mode, T, W, &per_cu)) return 1;
-        const double eff = (double)m / ((double)passes * W * T) * (4.22 / issue_cycles(per_cu * W / 4.0)) * (8.5 * T / (8.5 * T + 12.0));
-        if (eff > best_eff + 1e-9) {
-            best_eff = eff;
-            out->T = T; out->W = W; out->passes = passes; out->mpad = (uint32_t)(passes * W * T);
+        for (int W = 1; W <= maxW; ++W) {
+            if (c->opt_W > 0 && W != std::min(c->opt_W, maxW)) continue;
+            const int passes = (strips + W - 1) / W;
+            int per_cu = 1;
+            if (wgs_per_cu(c, mode, T, W, &per_cu)) return 1;
+            if (room_for_lane_waves && !c->opt_T) {
+                const int alloc = (c->regs_cache[(int)mode][T] + 7) / 8 * 8;
+                if (alloc * ((per_cu * W + 3) / 4) > 512 - 80) continue;
+            }
+            const double cost = (double)passes * T * W / kShapeGcups[ti][W - 1] * (passes > 1 ? (W >= 8 ? 1.025 : 1.17) : 1.0);
+            if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
+                best_cost = cost;
+                out->T = T; out->W = W; out->passes = passes; out->mpad = (uint32_t)(passes * W * T);
+            }
         }
     }
+    if (best_cost < 0) { fail("no kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W); return 1; }
     return 0;
 }
 
@@ -475,20 +491,19 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
     // query's end are zero, like the reference's dummy row 23
     const Mode main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 ? Mode::F16 : Mode::PK16);
-    // a database with a long-sequence tail keeps T=32: 3 bulk waves x 144 VGPRs leave exactly the 80 registers
-    // per SIMD lane that a lane-systolic wave needs to run beside them
-    int forced_T = (c->opt_T == 16 || c->opt_T == 24 || c->opt_T == 32) ? c->opt_T : 0;
-    if (!forced_T && c->opt_tail_mode != 2 && main_mode != Mode::I32) {
+    // a database with a long-sequence tail is searched with launch shapes that leave room for lane-systolic waves
+    bool lane_room = false;
+    if (c->opt_tail_mode != 2 && main_mode != Mode::I32) {
         uint32_t longest = 0;
         for (const GroupDesc &g : c->groups) longest = std::max(longest, g.ncols);
-        if (c->opt_tail_mode == 1 || (double)longest > 0.5 * (double)c->total_cols / c->num_cu) forced_T = 32;
+        lane_room = c->opt_tail_mode == 1 || (double)longest > 0.5 * (double)c->total_cols / c->num_cu;
     }
     std::vector<QueryPlan> qps(qn);
     size_t prof_elems = 0;
     for (uint32_t q = 0; q < qn; ++q) {
-        if (choose_plan(c, main_mode, c->qm[q], forced_T, &qps[q])) return 1;
+        if (choose_plan(c, main_mode, c->qm[q], lane_room, &qps[q])) return 1;
         if (getenv("SWIMM_HIP_DEBUG"))
-            fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (forced_T=%d)\n", q, c->qm[q], qps[q].T, qps[q].W, qps[q].passes, forced_T);
+            fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, c->qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
         const uint32_t lane_rows = (uint32_t)((c->qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
         qps[q].mpad = std::max(qps[q].mpad, lane_rows);
         qps[q].prof_off = prof_elems;
@@ -950,8 +965,11 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail("swimm_hip_set_option: NULL argument");
     if (!strcmp(key, "rows_per_wave")) {
-        if (value != 0 && value != 16 && value != 24 && value != 32) return fail("rows_per_wave must be 0 (auto), 16, 24 or 32");
+        if (value != 0 && (value < 8 || value > 36 || value % 4)) return fail("rows_per_wave must be 0 (auto) or a multiple of 4 in 8..36");
         c->opt_T = value;
+    } else if (!strcmp(key, "waves")) {
+        if (value < 0 || value > kMaxWaves) return fail("waves must be 0 (auto) .. %d", kMaxWaves);
+        c->opt_W = value;
     } else if (!strcmp(key, "max_waves")) {
         if (value < 0 || value > kMaxWaves) return fail("max_waves must be 0..%d", kMaxWaves);
         c->opt_maxW = value;

@@ -103,3 +103,17 @@ def test_chained_lane_passes_many_items():
     for opts in ({"tail_mode": 1}, {"tail_mode": 1, "f16": 0}):
         want, stats = run_case(seqs, [q1, q2], matrix="blosum50", opts=opts, max_chunk=200000)
         assert want.max() > 2048
+
+
+@pytest.mark.parametrize("T", [8, 12, 16, 20, 24, 28, 32, 36])
+def test_every_strip_height_vs_oracle(T):
+    """every rows-per-wave instantiation of the pipeline kernel, one pass and several, against the oracle;
+    query lengths sit on and around the strip boundaries"""
+    rng = np.random.default_rng(T)
+    seqs = [rnd(rng, int(n)) for n in rng.integers(1, 300, 260)]
+    base = rnd(rng, 4 * T + 3)
+    seqs += [base.copy(), np.concatenate([base[:T], rnd(rng, 5), base[T:]])]
+    queries = [base[:T - 1], base[:T], base[:T + 1], base[:2 * T], base[:3 * T + 2], base]
+    for W in (1, 3, 4):
+        run_case(seqs, queries, opts={"rows_per_wave": T, "waves": W, "tail_mode": 2})
+    run_case(seqs, queries, opts={"rows_per_wave": T})

@@ -96,7 +96,7 @@ def main():
                 st = s.last_stats()
                 print(json.dumps({"query_len": int(m[qi]), "ms": round(wt * 1e3, 3), "kernel_ms": round(st["kernel_ms"], 3),
                                   "gcups": round(int(m[qi]) * residues / wt / 1e9, 1), "launches": st["launches"],
-                                  "promoted": st["promoted"], "top1": int(ts[0, 0])}), flush=True)
+                                  "promoted": st["promoted"], "top1": int(ts[0, 0]), "plan": s.last_plan(0)}), flush=True)
         s.set_queries(a, m, disp, sm, 10, 2)
         best = None
         for _ in range(args.reps):

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include <string>
+#include <cstdlib>
 
 __device__ unsigned long long g_clk[2];
 #define ITER 2048
@@ -48,6 +49,29 @@ DEFINE_KERNEL(mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2")
 DEFINE_KERNEL(bfe_u32, "v_bfe_u32 %0, %0, %1, %2")
 DEFINE_KERNEL(max_u16_sdwa, "v_max_i16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1")
 
+DEFINE_KERNEL(pk_fmac_f16, "v_pk_fmac_f16 %0, %1, %2")
+DEFINE_KERNEL(fmac_f16, "v_mac_f16 %0, %1, %2")
+DEFINE_KERNEL(fmac_f32, "v_fmac_f32 %0, %1, %2")
+DEFINE_KERNEL(max_f16, "v_max_f16 %0, %0, %1")
+DEFINE_KERNEL(add_f16, "v_add_f16 %0, %0, %1")
+DEFINE_KERNEL(max_f32, "v_max_f32 %0, %0, %1")
+DEFINE_KERNEL(max_u32, "v_max_u32 %0, %0, %1")
+DEFINE_KERNEL(min_i32, "v_min_i32 %0, %0, %1")
+DEFINE_KERNEL(or_b32, "v_or_b32 %0, %0, %1")
+DEFINE_KERNEL(and_b32, "v_and_b32 %0, %0, %1")
+DEFINE_KERNEL(xor_b32, "v_xor_b32 %0, %0, %1")
+DEFINE_KERNEL(lshlrev_b32, "v_lshlrev_b32 %0, 3, %0")
+DEFINE_KERNEL(mov_b32, "v_mov_b32 %0, %1")
+DEFINE_KERNEL(add_u16, "v_add_u16 %0, %0, %1")
+DEFINE_KERNEL(sub_u16, "v_sub_u16 %0, %0, %1")
+DEFINE_KERNEL(max_u16, "v_max_u16 %0, %0, %1")
+DEFINE_KERNEL(mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
+DEFINE_KERNEL(sub_u32, "v_sub_u32 %0, %0, %1")
+DEFINE_KERNEL(pk_mul_f16, "v_pk_mul_f16 %0, %0, %1")
+DEFINE_KERNEL(pk_min_f16, "v_pk_min_f16 %0, %0, %1")
+DEFINE_KERNEL(pk_add_u16, "v_pk_add_u16 %0, %0, %1")
+DEFINE_KERNEL(dot2c_i32_i16, "v_dot2c_i32_i16 %0, %1, %2")
+
 typedef void (*kern_t)(uint32_t *, uint32_t);
 struct Entry { const char *name; kern_t k; };
 
@@ -60,7 +84,14 @@ int main()
         {"v_pk_max_f16", k_pk_max_f16}, {"v_pk_maximum3_f16", k_pk_maximum3_f16}, {"v_pk_fma_f16", k_pk_fma_f16},
         {"v_max_i16", k_max_i16}, {"v_add_f32", k_add_f32}, {"v_max3_f32", k_max3_f32}, {"v_mad_u32_u24", k_mad_u32_u24},
         {"v_bfe_u32", k_bfe_u32}, {"v_max_i16_sdwa", k_max_u16_sdwa},
+        {"v_pk_fmac_f16 (VOP2)", k_pk_fmac_f16}, {"v_mac_f16", k_fmac_f16}, {"v_fmac_f32", k_fmac_f32}, {"v_max_f16", k_max_f16},
+        {"v_add_f16", k_add_f16}, {"v_max_f32", k_max_f32}, {"v_max_u32", k_max_u32}, {"v_min_i32", k_min_i32}, {"v_or_b32", k_or_b32},
+        {"v_and_b32", k_and_b32}, {"v_xor_b32", k_xor_b32}, {"v_lshlrev_b32", k_lshlrev_b32}, {"v_mov_b32", k_mov_b32},
+        {"v_add_u16", k_add_u16}, {"v_sub_u16", k_sub_u16}, {"v_max_u16", k_max_u16}, {"v_mul_u32_u24", k_mul_u32_u24},
+        {"v_sub_u32", k_sub_u32}, {"v_pk_mul_f16", k_pk_mul_f16}, {"v_pk_min_f16", k_pk_min_f16}, {"v_pk_add_u16", k_pk_add_u16},
+        {"v_dot2c_i32_i16", k_dot2c_i32_i16},
     };
+    if (getenv("VALU_RATE_FROM")) ks.erase(ks.begin(), ks.begin() + atoi(getenv("VALU_RATE_FROM")));
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;

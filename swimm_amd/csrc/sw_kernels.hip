@@ -319,6 +319,11 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             STAMP(tB);
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) {
+                // The SIMD issues its OLDEST ready wave first, so waves that start a chunk together finish it one
+                // after the other and the last one runs alone (5.7 instead of 4.4 cycles per instruction).  A wave
+                // that is ahead lowers its own priority column by column, which keeps the SIMD's waves abreast.
+                if (jj == 0) __builtin_amdgcn_s_setprio(3); else if (jj == 1) __builtin_amdgcn_s_setprio(2);
+                else if (jj == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 const uint32_t da = (wa >> (8 * jj)) & 0xffu;
                 const unsigned char *pa = my_prof + da * PS;
                 const unsigned char *pb = pa;
@@ -539,6 +544,9 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     typedef typename Ops::V V;
     constexpr int TR = kLaneRows, C = kChunkCols, RP = 64 * TR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // these waves carry the critical path (the longest alignments, or the re-runs a query is waiting for) and share
+    // the SIMDs with bulk waves that run at priorities 3..0: keep them at the top
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int PS = prof_row_bytes(RP);
     const uint32_t pass = blockIdx.x / p.wg_per_pass;

@@ -190,22 +190,24 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
 // (tools/plan_sweep.py on one MI355X, profiles/r01_plan_sweep.txt).  W = 4, 8, 12, 16 put the same number of waves
 // on each of the CU's 4 SIMDs; any other W runs like the next multiple of 4 (2 x 6 waves behave like 4+4+2+2).
 static const float kShapeGcups[8][16] = {
-    {2750, 5011, 5273, 5995, 5156, 5460, 5891, 6738, 5749, 4414, 5880, 6347, 5738, 5909, 5432, 6724},   // T=8
-    {3455, 5329, 5554, 6314, 5038, 5725, 6351, 7053, 5764, 5955, 6496, 7076, 5305, 5648, 6059, 6496},   // T=12
-    {3955, 5667, 5644, 6935, 5552, 4427, 6127, 6993, 4925, 5459, 6007, 6543, 5695, 6098, 6527, 6960},   // T=16
-    {4292, 5877, 5850, 7186, 4716, 5540, 6427, 7278, 5140, 5676, 6225, 6820, 5768, 6335, 6769, 7246},   // T=20
-    {4555, 6083, 5792, 7406, 4948, 5664, 6570, 7430, 5270, 5872, 6444, 7036, 5978, 6495, 6961, 7461},   // T=24
-    {4606, 6096, 5846, 7497, 5402, 5768, 6682, 7613, 5454, 6019, 6651, 7223, 6171, 6619, 7115, 7560},   // T=28
-    {4803, 6226, 5959, 7301, 4340, 5161, 6015, 6854, 5540, 6095, 6729, 7326, 0, 0, 0, 0},               // T=32
-    {4775, 6275, 5682, 7403, 4395, 5243, 5951, 6971, 5589, 6200, 6407, 7454, 0, 0, 0, 0},               // T=36
+    {2345, 4100, 5262, 6672, 5488, 6244, 6419, 7310, 6545, 4730, 6576, 7028, 6468, 6462, 5550, 7228},     // T=8
+    {2934, 4856, 6092, 6866, 5743, 6710, 6660, 7613, 6173, 6458, 6933, 7469, 5702, 6102, 6566, 6991},     // T=12
+    {3321, 5424, 6321, 7340, 6218, 4582, 6754, 7699, 5293, 5855, 6448, 6988, 6076, 6504, 6951, 7389},     // T=16
+    {3532, 5822, 6498, 7553, 4236, 6184, 6711, 7728, 5494, 6125, 6691, 7314, 6128, 6730, 7175, 7666},     // T=20
+    {3821, 6222, 6574, 7792, 4576, 5977, 6865, 7812, 5701, 6334, 6904, 7534, 6354, 6902, 7367, 7858},     // T=24
+    {3894, 6324, 6576, 7843, 5170, 6048, 6996, 7951, 5826, 6462, 7081, 7721, 6539, 7028, 7514, 8031},     // T=28
+    {4068, 6751, 6763, 7739, 4596, 5486, 6402, 7284, 5892, 6530, 7171, 7801, 0, 0, 0, 0},                 // T=32
+    {4187, 6880, 6402, 7758, 4700, 5610, 6419, 7482, 6004, 6670, 6946, 7970, 0, 0, 0, 0},                 // T=36
 };
 
 // Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the shape with the lowest
-// predicted time per database column, passes x (T x W padded rows) / measured rate of that shape; with more than
-// one pass the strip boundaries go through HBM and the first wave waits for its loads: measured 2.5 % for
-// W >= 8, 17 % for the 4-wave shapes (c5-shaped shard, queries of 464 ... 5478 rows).  `room_for_lane_waves`: the database has a long-sequence
-// tail that the lane kernel aligns on a second stream while this kernel runs; only shapes that leave the 80
-// VGPRs per SIMD lane a lane-systolic wave needs are admitted (e.g. 3 waves x 144, 4 x 104).
+// predicted time per database column, passes x (T x W padded rows) / measured rate of that shape.  With more than
+// one pass the strip boundaries go through HBM and the first wave waits for its loads: not measurable for W >= 8
+// (every query of 464 ... 5478 rows on a c5-shaped shard runs at 0.97 of its shape's rate, like the one-pass
+// ones), 17 % for the 4-wave shapes.
+// `room_for_lane_waves`: the database has a long-sequence tail that the lane kernel aligns on a second stream
+// while this kernel runs; only shapes that leave the 80 VGPRs per SIMD lane a lane-systolic wave needs are
+// admitted (e.g. 3 waves x 144, 4 x 104).
 int choose_plan(const swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, QueryPlan *out)
 {
     double best_cost = -1;
@@ -225,7 +227,7 @@ int choose_plan(const swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_wav
                 const int alloc = (c->regs_cache[(int)mode][T] + 7) / 8 * 8;
                 if (alloc * ((per_cu * W + 3) / 4) > 512 - 80) continue;
             }
-            const double cost = (double)passes * T * W / kShapeGcups[ti][W - 1] * (passes > 1 ? (W >= 8 ? 1.025 : 1.17) : 1.0);
+            const double cost = (double)passes * T * W / kShapeGcups[ti][W - 1] * (passes > 1 ? (W >= 8 ? 1.005 : 1.17) : 1.0);
             if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
                 best_cost = cost;
                 out->T = T; out->W = W; out->passes = passes; out->mpad = (uint32_t)(passes * W * T);

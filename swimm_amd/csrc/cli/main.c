@@ -62,6 +62,119 @@ static void shard_chunks(const swimm_chunks *ch, int gpus, int *owner)
     free(order);
 }
 
+typedef struct { double kernel_ms, seconds; uint64_t promoted; uint32_t chunk_count; } leg_stats;
+
+/* Host leg (mode 0, and the host's share in mode 2): `count` sequences starting at the short end of the sorted
+ * database; per query the first `top` rows of the listing, indices = sorted-database indices.  The lane-interleaved
+ * copy of the database is built by the caller beforehand (untimed, like swimm.c:46 before the search call). */
+static void cpu_leg(const swimm_options *o, const swimm_queries *q, const char *submat, const swimm_single_chunk *sc,
+                    uint64_t count, unsigned long top, int32_t *out_s, int64_t *out_i, leg_stats *st)
+{
+    const uint64_t stride = sc->vc * (uint64_t)o->vector_length;
+    int32_t *scores = (int32_t *)malloc(q->count * stride * sizeof(int32_t));
+    if (!scores) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
+    int rc = swimm_cpu_search(q->a, q->m, q->count, q->disp, sc->b, sc->n, sc->vc, sc->disp, submat, o->open_gap, o->extend_gap,
+                              o->cpu_threads, o->cpu_block_size, o->vector_length, scores, &st->seconds);
+    if (rc) die_host(rc);
+    for (uint64_t i = 0; i < q->count; ++i)   /* sort_scores + first `top` rows, swimm.c:151-160 */
+        swimm_topr(scores + i * stride, count, (uint32_t)top, out_s + i * top, out_i + i * top);
+    free(scores);
+}
+
+/* GPU leg: the chunks `ch` (assembled by the caller from `count` sequences of the sorted database starting at
+ * sequence `first`) dealt to o->num_gpus devices; per device and query the first `top` rows, lists laid out
+ * [device][query][top], indices global. */
+static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swimm_queries *q, const char *submat,
+                    const swimm_chunks *chp, uint64_t count, uint64_t first, unsigned long top,
+                    int32_t *part_s, int64_t *part_i, leg_stats *st)
+{
+    const double tick = swimm_wtime();
+    const int G = o->num_gpus;
+    const swimm_chunks ch = *chp;
+    st->chunk_count = ch.chunk_count;
+    int *owner = (int *)malloc(ch.chunk_count * sizeof(int));
+    shard_chunks(&ch, G, owner);
+    char (*gerr)[512] = calloc((size_t)G, 512);
+    double *g_kms = (double *)calloc((size_t)G, sizeof(double));
+    uint64_t *g_prom = (uint64_t *)calloc((size_t)G, sizeof(uint64_t));
+#pragma omp parallel num_threads(G)
+    {
+        const int g = omp_get_thread_num();
+        swimm_hip_ctx *ctx = NULL;
+        int mine = 0;
+        for (uint32_t c = 0; c < ch.chunk_count; ++c) mine += owner[c] == g;
+        int bad = 0;
+        if (mine == 0) bad = -1;   /* nothing to do on this device */
+        const double t0 = swimm_wtime();
+        if (!bad && api->create(g, &ctx)) bad = 1;
+        const double t1 = swimm_wtime();
+        if (!bad && api->set_queries(ctx, q->a, q->m, q->disp, (uint32_t)q->count, submat, o->open_gap, o->extend_gap)) bad = 1;
+        for (uint32_t c = 0; !bad && c < ch.chunk_count; ++c)
+            if (owner[c] == g && api->add_chunk(ctx, ch.chunk_b[c], ch.chunk_vD[c], ch.chunk_n[c], ch.chunk_disp[c],
+                                                ch.chunk_groups[c], 128, ch.chunk_first_group[c])) bad = 1;
+        const double t2 = swimm_wtime();
+        int32_t *ps = part_s + (size_t)g * q->count * top;
+        int64_t *pi = part_i + (size_t)g * q->count * top;
+        if (!bad && api->search_topr(ctx, (uint32_t)top, count, ps, pi, NULL)) bad = 1;
+        if (getenv("SWIMM_DEBUG"))
+            fprintf(stderr, "swimm: GPU %d: context %.3f s, upload %.3f s, search %.3f s\n", g, t1 - t0, t2 - t1, swimm_wtime() - t2);
+        if (bad > 0) snprintf(gerr[g], 512, "%s", api->last_error());
+        if (!bad) {
+            api->last_stats(ctx, &g_kms[g], NULL, &g_prom[g], NULL);
+            for (size_t i = 0; i < q->count * top; ++i) if (pi[i] >= 0) pi[i] += (int64_t)first;
+        }
+        if (ctx) api->destroy(ctx);
+    }
+    for (int g = 0; g < G; ++g) if (gerr[g][0]) { printf("SWIMM: GPU %d: %s\n", g, gerr[g]); exit(5); }
+    for (int g = 0; g < G; ++g) { if (g_kms[g] > st->kernel_ms) st->kernel_ms = g_kms[g]; st->promoted += g_prom[g]; }
+    free(gerr); free(g_kms); free(g_prom); free(owner);
+    st->seconds = swimm_wtime() - tick;
+}
+
+/* Mode 2 (the reference's het_search_*, HETsearch.c:57,96-104: host and devices pull chunks from one queue): here
+ * the split is fixed before the search, because the GPUs keep their share resident and search it in one go.  The
+ * host's rate is measured on a sample of the shortest sequences, the GPUs' is taken as SWIMM_HYBRID_GPU_GCUPS (default
+ * 6500 per device, plus start-up and upload time); the host gets the shortest sequences it can finish in the time
+ * the GPUs need for the rest.  Returns the number of sequences for the host (0: not worth it). */
+static uint64_t hybrid_split(const swimm_options *o, const swimm_queries *q, const char *submat, const swimm_db *db, int G)
+{
+    const uint64_t vl = (uint64_t)o->vector_length;
+    const char *forced = getenv("SWIMM_HYBRID_CPU_SEQUENCES");   /* test hook: fixed host share */
+    if (forced) {
+        uint64_t n = strtoull(forced, NULL, 10) / 128 * 128;
+        return n < db->count ? n : 0;
+    }
+    uint64_t sample = 0, sample_res = 0;
+    while (sample < db->count && sample_res * q->m[0] < 100000000ull) sample_res += db->lengths[sample++];
+    sample = sample / vl * vl;
+    if (sample == 0 || sample == db->count) return 0;
+    swimm_queries q0 = *q;
+    q0.count = 1;                                   /* first (shortest) query only */
+    leg_stats st = {0, 0, 0, 0};
+    int32_t s1[1];
+    int64_t i1[1];
+    swimm_single_chunk sc;
+    int rc = swimm_assemble_single_chunk(db->lengths, db->codes, sample, o->vector_length, o->cpu_block_size, &sc);
+    if (rc) die_host(rc);
+    cpu_leg(o, &q0, submat, &sc, sample, 1, s1, i1, &st);
+    swimm_single_chunk_free(&sc);
+    sample_res = 0;
+    for (uint64_t i = 0; i < sample; ++i) sample_res += db->lengths[i];
+    const double host_rate = (double)sample_res * q->m[0] / (st.seconds > 1e-6 ? st.seconds : 1e-6);   /* cells per second */
+    const char *env = getenv("SWIMM_HYBRID_GPU_GCUPS");
+    const double gpu_rate = (env && atof(env) > 0 ? atof(env) : 6500.0) * 1e9 * G;
+    const double fixed = 0.10 + (double)db->residues / G / 15e9;   /* context creation + pageable upload, measured 0.03 s + 17 GB/s */
+    const double Qrows = (double)q->Q;
+    /* host_cells / host_rate = fixed + (total - host_cells) / gpu_rate */
+    const double total = Qrows * (double)db->residues;
+    double host_cells = (fixed + total / gpu_rate) / (1.0 / host_rate + 1.0 / gpu_rate);
+    if (host_cells > 0.5 * total) host_cells = 0.5 * total;
+    uint64_t n = 0, res = 0;
+    while (n < db->count && (double)(res + db->lengths[n]) * Qrows <= host_cells) res += db->lengths[n++];
+    n = n / 128 * 128;                               /* the GPU part keeps whole lane groups */
+    return n >= vl && n < db->count ? n : 0;
+}
+
 int main(int argc, char **argv)
 {
     swimm_options o;
@@ -73,7 +186,7 @@ int main(int argc, char **argv)
     printf("Database file:\t\t\t%s\n", o.db_prefix);
 
     const char *submat = swimm_submat(o.submat_name);
-    const int gpu_mode = o.execution_mode == MODE_GPU_ONLY;
+    const int gpu_mode = o.execution_mode != MODE_CPU_ONLY;
     if (o.cpu_block_size == 0) o.cpu_block_size = (o.vector_length == 32 ? 64 : 128) / SWIMM_SEQ_LEN_MULT * SWIMM_SEQ_LEN_MULT;   /* swimm.c:32-35 */
 
     /* mode 0 pads odd queries to even length (sequences.c:378-387); the accelerator mode does not (347-364) */
@@ -95,23 +208,17 @@ int main(int argc, char **argv)
     int32_t *top_scores = (int32_t *)malloc(q.count * top * sizeof(int32_t));
     int64_t *top_idx = (int64_t *)malloc(q.count * top * sizeof(int64_t));
     if (!top_scores || !top_idx) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
-    double workTime = 0, kernel_ms = 0;
-    uint64_t promoted = 0;
-    uint32_t chunk_count = 0;
+    double workTime = 0;
+    leg_stats gst = {0, 0, 0, 0}, cst = {0, 0, 0, 0};
+    uint64_t n_cpu = 0;          /* sequences (from the short end of the sorted database) searched on the host */
     omp_set_num_threads(o.cpu_threads);
 
-    if (!gpu_mode) {
+    if (o.execution_mode == MODE_CPU_ONLY) {
         swimm_single_chunk sc;
         if ((rc = swimm_assemble_single_chunk(db.lengths, db.codes, db.count, o.vector_length, o.cpu_block_size, &sc))) die_host(rc);
-        const uint64_t stride = sc.vc * (uint64_t)o.vector_length;
-        int32_t *scores = (int32_t *)malloc(q.count * stride * sizeof(int32_t));
-        if (!scores) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
-        if ((rc = swimm_cpu_search(q.a, q.m, q.count, q.disp, sc.b, sc.n, sc.vc, sc.disp, submat, o.open_gap, o.extend_gap,
-                                   o.cpu_threads, o.cpu_block_size, o.vector_length, scores, &workTime))) die_host(rc);
-        for (uint64_t i = 0; i < q.count; ++i)   /* sort_scores + first `top` rows, swimm.c:151-160 */
-            swimm_topr(scores + i * stride, db.count, (uint32_t)top, top_scores + i * top, top_idx + i * top);
-        free(scores);
+        cpu_leg(&o, &q, submat, &sc, db.count, top, top_scores, top_idx, &cst);
         swimm_single_chunk_free(&sc);
+        workTime = cst.seconds;   /* the search call only, like CPUsearch.c:530,960 */
     } else {
         swimm_hip_api api;
         char err[1024];
@@ -119,53 +226,44 @@ int main(int argc, char **argv)
         const int avail = api.device_count();
         if (avail <= 0) { printf("SWIMM: no MI355X visible: %s\n", api.last_error()); exit(5); }
         if (o.num_gpus > avail) { printf("SWIMM: %d GPUs requested, %d visible.\n", o.num_gpus, avail); exit(5); }
-        swimm_chunks ch;
-        if ((rc = swimm_assemble_chunks(db.lengths, db.codes, db.count, 128, o.max_chunk_size, &ch))) die_host(rc);
-        chunk_count = ch.chunk_count;
         const int G = o.num_gpus;
-        int *owner = (int *)malloc(ch.chunk_count * sizeof(int));
-        shard_chunks(&ch, G, owner);
-        int32_t *part_s = (int32_t *)malloc((size_t)G * q.count * top * sizeof(int32_t));
-        int64_t *part_i = (int64_t *)malloc((size_t)G * q.count * top * sizeof(int64_t));
-        char (*gerr)[512] = calloc((size_t)G, 512);
-        double *g_kms = (double *)calloc((size_t)G, sizeof(double));
-        uint64_t *g_prom = (uint64_t *)calloc((size_t)G, sizeof(uint64_t));
-        for (size_t i = 0; i < (size_t)G * q.count * top; ++i) { part_s[i] = -1; part_i[i] = -1; }
+        if (o.execution_mode == MODE_HYBRID) n_cpu = hybrid_split(&o, &q, submat, &db, G);
+        const uint64_t n_gpu = db.count - n_cpu;
+        uint64_t cpu_residues = 0;
+        for (uint64_t i = 0; i < n_cpu; ++i) cpu_residues += db.lengths[i];
+        const int lists = G + (n_cpu ? 1 : 0);
+        int32_t *part_s = (int32_t *)malloc((size_t)lists * q.count * top * sizeof(int32_t));
+        int64_t *part_i = (int64_t *)malloc((size_t)lists * q.count * top * sizeof(int64_t));
+        if (!part_s || !part_i) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
+        for (size_t i = 0; i < (size_t)lists * q.count * top; ++i) { part_s[i] = -1; part_i[i] = -1; }
+        swimm_chunks ch;            /* both layouts are built before the clock starts (swimm.c:46 precedes the search call) */
+        swimm_single_chunk sc;
+        if ((rc = swimm_assemble_chunks(db.lengths + n_cpu, db.codes + cpu_residues, n_gpu, 128, o.max_chunk_size, &ch))) die_host(rc);
+        if (n_cpu && (rc = swimm_assemble_single_chunk(db.lengths, db.codes, n_cpu, o.vector_length, o.cpu_block_size, &sc))) die_host(rc);
         const double tick = swimm_wtime();   /* brackets transfers + kernels + merge, like MICsearch.c:51,350 */
-#pragma omp parallel num_threads(G)
+        omp_set_max_active_levels(2);
+#pragma omp parallel sections num_threads(2)
         {
-            const int g = omp_get_thread_num();
-            swimm_hip_ctx *ctx = NULL;
-            int mine = 0;
-            for (uint32_t c = 0; c < ch.chunk_count; ++c) mine += owner[c] == g;
-            int bad = 0;
-            if (mine == 0) bad = -1;   /* nothing to do on this device */
-            if (!bad && api.create(g, &ctx)) bad = 1;
-            if (!bad && api.set_queries(ctx, q.a, q.m, q.disp, (uint32_t)q.count, submat, o.open_gap, o.extend_gap)) bad = 1;
-            for (uint32_t c = 0; !bad && c < ch.chunk_count; ++c)
-                if (owner[c] == g && api.add_chunk(ctx, ch.chunk_b[c], ch.chunk_vD[c], ch.chunk_n[c], ch.chunk_disp[c],
-                                                   ch.chunk_groups[c], 128, ch.chunk_first_group[c])) bad = 1;
-            if (!bad && api.search_topr(ctx, (uint32_t)top, db.count, part_s + (size_t)g * q.count * top,
-                                        part_i + (size_t)g * q.count * top, NULL)) bad = 1;
-            if (bad > 0) snprintf(gerr[g], 512, "%s", api.last_error());
-            if (!bad) api.last_stats(ctx, &g_kms[g], NULL, &g_prom[g], NULL);
-            if (ctx) api.destroy(ctx);
+#pragma omp section
+            gpu_leg(&api, &o, &q, submat, &ch, n_gpu, n_cpu, top, part_s, part_i, &gst);
+#pragma omp section
+            if (n_cpu) cpu_leg(&o, &q, submat, &sc, n_cpu, top, part_s + (size_t)G * q.count * top,
+                               part_i + (size_t)G * q.count * top, &cst);
         }
-        for (int g = 0; g < G; ++g) if (gerr[g][0]) { printf("SWIMM: GPU %d: %s\n", g, gerr[g]); exit(5); }
-        /* host k-way merge of the per-GPU lists: per query, lists are [G][top] */
-        int32_t *ls = (int32_t *)malloc((size_t)G * top * sizeof(int32_t));
-        int64_t *li = (int64_t *)malloc((size_t)G * top * sizeof(int64_t));
+        swimm_chunks_free(&ch);
+        if (n_cpu) swimm_single_chunk_free(&sc);
+        /* host k-way merge of the per-device lists ([lists][query][top]) */
+        int32_t *ls = (int32_t *)malloc((size_t)lists * top * sizeof(int32_t));
+        int64_t *li = (int64_t *)malloc((size_t)lists * top * sizeof(int64_t));
         for (uint64_t i = 0; i < q.count; ++i) {
-            for (int g = 0; g < G; ++g) {
+            for (int g = 0; g < lists; ++g) {
                 memcpy(ls + (size_t)g * top, part_s + ((size_t)g * q.count + i) * top, top * sizeof(int32_t));
                 memcpy(li + (size_t)g * top, part_i + ((size_t)g * q.count + i) * top, top * sizeof(int64_t));
             }
-            swimm_topr_merge(ls, li, (uint32_t)G, (uint32_t)top, top_scores + i * top, top_idx + i * top);
+            swimm_topr_merge(ls, li, (uint32_t)lists, (uint32_t)top, top_scores + i * top, top_idx + i * top);
         }
         workTime = swimm_wtime() - tick;
-        for (int g = 0; g < G; ++g) { if (g_kms[g] > kernel_ms) kernel_ms = g_kms[g]; promoted += g_prom[g]; }
-        free(ls); free(li); free(part_s); free(part_i); free(gerr); free(g_kms); free(g_prom); free(owner);
-        swimm_chunks_free(&ch);
+        free(ls); free(li); free(part_s); free(part_i);
     }
 
     /* titles of the reported hits only (the reference loads all N, sequences.c:757-761) */
@@ -182,18 +280,24 @@ int main(int argc, char **argv)
     printf("\nSearch date:\t\t\t%s", ctime(&current_time));
     printf("Search time:\t\t\t%lf seconds\n", workTime);
     printf("Search speed:\t\t\t%.2lf GCUPS\n", ((double)q.Q * (double)db.residues) / (workTime * 1000000000));
-    if (!gpu_mode) {
+    if (o.execution_mode == MODE_CPU_ONLY) {
         printf("Execution mode:\t\t\tHost CPU only (%d threads, block width = %d)\n", o.cpu_threads, o.cpu_block_size);
         printf("Profile technique:\t\tSubstitution row per query residue\n");
         printf("Instruction set:\t\tcompiler-vectorised int32 lanes (vector length = %d)\n", o.vector_length);
     } else {
-        printf("Execution mode:\t\t\tMI355X only (%d GPUs)\n", o.num_gpus);
+        if (o.execution_mode == MODE_HYBRID)
+            printf("Execution mode:\t\t\tConcurrent host CPU and MI355X (%d CPU threads and %d GPUs)\n", o.cpu_threads, o.num_gpus);
+        else
+            printf("Execution mode:\t\t\tMI355X only (%d GPUs)\n", o.num_gpus);
         printf("Profile technique:\t\tQuery Profile in LDS\n");
         printf("Instruction set:\t\tgfx950 packed binary16 -> int16 -> int32 ladder (vector length = 128)\n");
         printf("Max. chunk size:\t\t%ld bytes\n", o.max_chunk_size);
-        printf("Chunk count:\t\t\t%ld \n", (long)chunk_count);
-        printf("Kernel time:\t\t\t%lf seconds\n", kernel_ms / 1000.0);
-        printf("Promoted to int32:\t\t%ld alignments\n", (long)promoted);
+        printf("Chunk count:\t\t\t%ld \n", (long)gst.chunk_count);
+        printf("Kernel time:\t\t\t%lf seconds\n", gst.kernel_ms / 1000.0);
+        printf("Promoted to int32:\t\t%ld alignments\n", (long)gst.promoted);
+        if (o.execution_mode == MODE_HYBRID)   /* the reference prints "%d chunks in CPU and %d in MICs" (HETsearch.c:337-342) */
+            printf("Host CPU share:\t\t\t%ld sequences (%.2lf seconds), MI355X %ld sequences (%.2lf seconds)\n", (long)n_cpu, cst.seconds,
+                   (long)(db.count - n_cpu), gst.seconds);
     }
     for (uint64_t i = 0; i < q.count * top; ++i) free(titles[i]);
     free(titles); free(top_scores); free(top_idx);

@@ -25,7 +25,7 @@ static struct argp_option options[] = {
     {"sm", 's', "<string>", 0, "Substitution matrix. Supported values: blosum45, blosum50, blosum62, blosum80, blosum90, pam30, pam70, pam250 (default: blosum62).", 3},
     {"gap_open", 'g', "<integer>", 0, "Gap open penalty (default: 10).", 3},
     {"gap_extend", 'e', "<integer>", 0, "Gap extend penalty (default: 2).", 3},
-    {"execution_mode", 'm', "<integer>", 0, "Execution mode: 0 for host CPU only, 1 for MI355X only (default: 1). Mode 2 (CPU+accelerator) is not available in this build.", 3},
+    {"execution_mode", 'm', "<integer>", 0, "Execution mode: 0 for host CPU only, 1 for MI355X only, 2 for concurrent host CPU and MI355X (default: 1).", 3},
     {"cpu_threads", 'c', "<integer>", 0, "Number of host threads (default: 4).", 3},
     {"num_gpus", 'x', "<integer>", 0, "Number of MI355X GPUs. Valid option only when execution mode is 1 (default: 1).", 3},
     {"mic_threads", 't', "<integer>", 0, "Accepted for compatibility; ignored (the GPU schedules its own wavefronts).", 3},
@@ -113,8 +113,6 @@ static int parse_opt(int key, char *arg, struct argp_state *state)
         } else {
             if (!o->db_prefix) argp_failure(state, 1, 0, "Database filename is required");
             if (!o->queries_filename) argp_failure(state, 1, 0, "Query sequences filename is required");
-            if (o->execution_mode == MODE_HYBRID)
-                argp_failure(state, 1, 0, "Execution mode 2 (CPU + accelerator) is not available in this build; use -m 1 (MI355X) or -m 0 (host CPU).");
             if (o->open_gap + o->extend_gap > 127)
                 argp_failure(state, 1, 0, "Gap open + gap extend must not exceed 127.");
         }

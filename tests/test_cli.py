@@ -92,7 +92,7 @@ def test_cpu_search_library_all_cases(dbprefix, golden):
 
 def test_flag_validation(dbprefix, golden):
     q = os.path.join(GOLDEN, golden["query_fasta"])
-    assert run("-S", "search", "-q", q, "-d", dbprefix, "-m", "2", check=False).returncode == 1   # hybrid not built
+    assert run("-S", "search", "-q", q, "-d", dbprefix, "-m", "3", check=False).returncode == 1
     assert run("-S", "search", "-q", q, "-d", dbprefix, "-s", "blosum99", check=False).returncode == 1
     assert run("-S", "search", "-q", q, "-d", dbprefix, "-g", "100", "-e", "100", check=False).returncode == 1
     assert run("-S", "search", "-q", q, "-d", dbprefix, "-v", "64", "-m", "0", check=False).returncode == 1
@@ -104,11 +104,12 @@ def test_flag_validation(dbprefix, golden):
     assert p.returncode == 2
 
 
-def test_gpu_mode_fails_loudly_without_backend(dbprefix, golden, tmp_path):
-    """mode 1 with no usable back-end is an error, never a CPU fallback"""
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_gpu_mode_fails_loudly_without_backend(dbprefix, golden, tmp_path, mode):
+    """modes 1 and 2 with no usable back-end are an error, never a CPU fallback"""
     q = os.path.join(GOLDEN, golden["query_fasta"])
     env = dict(os.environ, SWIMM_HIP_LIB=str(tmp_path / "nope.so"))
-    p = subprocess.run([SWIMM, "-S", "search", "-q", q, "-d", dbprefix, "-m", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    p = subprocess.run([SWIMM, "-S", "search", "-q", q, "-d", dbprefix, "-m", mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     assert p.returncode == 5 and "cannot load the MI355X back-end" in p.stdout
     assert "Query no." not in p.stdout
 
@@ -121,3 +122,17 @@ def test_search_mode1_gpu_listing(dbprefix, golden):
     assert "Execution mode:\t\t\tMI355X only (1 GPUs)\n" in p.stdout and "Promoted to int32:\t\t1 alignments\n" in p.stdout
     p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-r", "413", "-s", "blosum50")   # r > 64: host selection path
     check_listing(p.stdout, golden, dbprefix, "blosum50_g10_e2", 413)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host_share", ["128", "256", "0"])
+def test_search_mode2_hybrid_listing(dbprefix, golden, host_share):
+    """mode 2: the shortest sequences on the host CPU, the rest on the GPU, one merged listing (HETsearch.c)"""
+    q = os.path.join(GOLDEN, golden["query_fasta"])
+    env = dict(os.environ, SWIMM_HYBRID_CPU_SEQUENCES=host_share)
+    p = subprocess.run([SWIMM, "-S", "search", "-q", q, "-d", dbprefix, "-m", "2", "-c", "4", "-r", "413"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    check_listing(p.stdout, golden, dbprefix, "blosum62_g10_e2", 413)
+    assert "Execution mode:\t\t\tConcurrent host CPU and MI355X (4 CPU threads and 1 GPUs)\n" in p.stdout
+    assert f"Host CPU share:\t\t\t{host_share} sequences" in p.stdout

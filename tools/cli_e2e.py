@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 from swimm_amd import synth  # noqa: E402
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
+extra = sys.argv[2:] or ["-c", "16"]          # e.g. -m 2 -c 16
 swimm = os.path.join(ROOT, "swimm_amd", "bin", "swimm")
 with tempfile.TemporaryDirectory() as tmp:
     qs = [synth.make_queries(2)[i] for i in (0, 3, 9)]
@@ -27,8 +28,8 @@ with tempfile.TemporaryDirectory() as tmp:
     out = subprocess.run([swimm, "-S", "preprocess", "-i", os.path.join(tmp, "db.fa"), "-o", os.path.join(tmp, "db")], capture_output=True, text=True)
     print(out.stdout.strip().split("\n")[-1], f"(wall {time.time() - t0:.1f} s)", flush=True)
     t0 = time.time()
-    out = subprocess.run([swimm, "-S", "search", "-q", os.path.join(tmp, "q.fa"), "-d", os.path.join(tmp, "db"), "-r", "5", "-c", "16"], capture_output=True, text=True)
-    print(out.stdout[-1800:], f"\n(search wall {time.time() - t0:.1f} s, rc {out.returncode})", flush=True)
+    out = subprocess.run([swimm, "-S", "search", "-q", os.path.join(tmp, "q.fa"), "-d", os.path.join(tmp, "db"), "-r", "5"] + extra, capture_output=True, text=True)
+    print(out.stderr[-600:], out.stdout[-1800:], f"\n(search wall {time.time() - t0:.1f} s, rc {out.returncode})", flush=True)
     assert out.returncode == 0, out.stderr
     for title, _ in qs:
         acc = title.split("|")[1]

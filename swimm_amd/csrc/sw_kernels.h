@@ -30,8 +30,12 @@ struct Item {
 struct PipeParams {
     const GroupDesc *groups;
     const Item *items;
-    const uint32_t *wg_first;   // [n_wg + 1] item ranges
-    const uint32_t *wg_chunks;  // [n_wg] total column chunks per workgroup
+    const uint32_t *wg_first;   // static partition: [n_wg + 1] item ranges
+    const uint32_t *wg_chunks;  // static partition: [n_wg] total column chunks per workgroup
+    uint32_t *queue;            // dynamic queue: cursor into items[] (sorted longest first), zeroed before the launch;
+                                // nullptr selects the static partition
+    uint32_t n_items;           // dynamic queue: length of items[]
+    uint32_t max_steps;         // dynamic queue: upper bound of a workgroup's loop (all chunks of the list + waves)
     const int16_t *prof;        // query profile prof[d * prof_stride + row]
     uint32_t prof_stride;       // rows allocated per code (>= passes * W * T)
     uint32_t r0;                // first query row of this pass
@@ -39,7 +43,7 @@ struct PipeParams {
     int first_pass, last_pass;
     int32_t *out;               // packed mode: score row of this query; int32 mode: out32
     int goe, ge;                // open+extend, extend
-    uint32_t *err;              // pipeline watchdog: set non-zero if a bounded LDS wait ever expires
+    uint32_t *err;              // watchdog word shared with the lane kernel
     unsigned long long *stamps; // diagnostic build only (-DSWIMM_STAMPS): per-wave-index cycle sums [16][8]
 };
 
@@ -74,16 +78,17 @@ struct LaneParams {
     int32_t *out;
     int goe, ge;
     uint32_t *err;              // watchdog word
+    int high_prio;              // 1: waves run at s_setprio 3 (re-runs a query is waiting for); 0: beside the bulk at priority 0
 };
 size_t lane_lds_bytes();
 hipError_t launch_lane(Mode mode, int n_wg, const LaneParams &p, hipStream_t s);
 
-size_t pipe_lds_bytes(int rows_per_wave, int waves, bool flag_sync);
+size_t pipe_lds_bytes(int rows_per_wave, int waves);
 // which (tier, rows per wave, hand-over scheme) kernels exist
-bool pipe_has_variant(Mode mode, int rows_per_wave, bool flag_sync);
+bool pipe_has_variant(Mode mode, int rows_per_wave);
 // registers / occupancy of one instantiation (for the host-side launch plan)
 hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, int *num_regs);
-hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, bool flag_sync, int n_wg, const PipeParams &p, hipStream_t s);
+hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, int n_wg, const PipeParams &p, hipStream_t s);
 
 // Re-tile one reference-layout chunk (sequences.c:506-526 byte interleave) into device groups.
 hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t vl_groups, uint32_t vl,

@@ -152,40 +152,38 @@ __host__ __device__ constexpr size_t round16(size_t x) { return (x + 15) & ~(siz
 // ds_read_b128 only when d == d' (mod 16)
 __host__ __device__ constexpr int prof_row_bytes(int rows) { return rows * 2 + 16; }
 
-// ring slots per wave: 2 with one workgroup barrier per chunk, kFlagRing when neighbouring waves hand
-// chunks over through LDS counters and may drift apart by that many chunks
-constexpr int kFlagRing = 4;
 // a wave's strip of T rows occupies round8(T) rows of the LDS profile, so that its ds_read_b128 stay 16-byte aligned
 __host__ __device__ constexpr int strip_lds_rows(int T) { return (T + 7) & ~7; }
-size_t pipe_lds_bytes(int T, int W, bool flag_sync)
+// LDS of one workgroup: query profile | hand-over ring (2 chunk slots per wave) | control words
+constexpr int kSeqRing = 32;      // item ids of the workgroup's sequence, published by wave 0 (dynamic mode)
+size_t pipe_lds_bytes(int T, int W)
 {
-    return round16((size_t)kCodes * prof_row_bytes(strip_lds_rows(T) * W)) + (size_t)W * (flag_sync ? kFlagRing : 2) * kChunkCols * 64 * sizeof(uint2) + 128;
+    return round16((size_t)kCodes * prof_row_bytes(strip_lds_rows(T) * W)) + (size_t)W * 2 * kChunkCols * 64 * sizeof(uint2) + (kSeqRing + 4) * 4;
 }
 
-// bounded wait on an LDS counter another wave of the same workgroup advances (all waves of a workgroup are
-// resident, so this always makes progress; the bound only turns a logic error into an error code instead of a hang)
-__device__ __forceinline__ bool wait_counter_above(const uint32_t *ctr, uint32_t need)
+constexpr uint32_t kNoItem = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t x)
 {
-    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
-        if (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *q) { return (const uint8_t *)(uintptr_t)uniform_u64((uint64_t)(uintptr_t)q); }
 
 // M: 0 = packed int16, 1 = int32 (one sequence per lane), 2 = packed f16
-// FS: false = one workgroup barrier per chunk (default); true = producer/consumer counters between
-//     neighbouring waves, ring of kFlagRing chunks.  Stamps show that the hardware issues the OLDEST ready
-//     wave first, so with a barrier the three waves of a SIMD finish a chunk one after the other (6 000 /
-//     9 700 / 14 100 cycles); letting the early waves run ahead through counters did NOT help (A/B in one
-//     process: 32.06 vs 31.55 ms on c2): the VALU is already kept as busy as three waves can keep it.
-template <int T, int M, bool FS>
+// DYN: false = the workgroup walks the item range the host gave it (static partition, longest first onto the
+//      least-loaded workgroup); true = wave 0 pulls the next item from a global cursor over the list sorted longest
+//      first and publishes its id to the other waves through LDS.  Same schedule when every CU runs at the same
+//      speed; when some CUs are slowed down (lane-systolic waves of the tail kernel share their SIMDs) the dynamic
+//      queue keeps all workgroups busy to the end.
+// The waves of a workgroup hand chunks over through an LDS ring with one workgroup barrier per chunk.  (Counters
+// between neighbouring waves instead of the barrier were tried and lost 1.5 %, see DESIGN.md.)
+template <int T, int M, bool DYN>
 __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
 {
     static_assert(T % 4 == 0 && T >= 8, "strips are multiples of 4 rows");
     constexpr int TP = strip_lds_rows(T);
     constexpr bool PK = M != 1;
-    constexpr int R = FS ? kFlagRing : 2;
     typedef typename std::conditional<M == 0, OpsPK, typename std::conditional<M == 1, OpsI32, OpsF16>::type>::type Ops;
     typedef typename Ops::V V;
     constexpr int C = kChunkCols;
@@ -198,9 +196,8 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     const int PS = prof_row_bytes(RW);
     unsigned char *prof_lds = smem;
     uint2 *ring = (uint2 *)(smem + round16((size_t)kCodes * PS));
-    uint32_t *prod = (uint32_t *)(ring + (size_t)W * R * C * 64);   // prod[k]: chunks wave k has published
-    uint32_t *cons = prod + 16;                                     // cons[k]: chunks wave k has taken from wave k-1
-    if (threadIdx.x < 32) prod[threadIdx.x] = 0;
+    uint32_t *seq = (uint32_t *)(ring + (size_t)W * 2 * C * 64);     // seq[n % kSeqRing]: id of the workgroup's n-th item
+    int *total_lds = (int *)(seq + kSeqRing);                          // chunks in the workgroup's whole sequence, once known
 
     // stage this pass's window of the query profile: rows [r0, r0 + W*T) of all 25 codes, strip k at LDS row k*TP
     {
@@ -222,13 +219,35 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             *(uint32_t *)(prof_lds + d * PS + x * 4) = v;
         }
     }
-    __syncthreads();
+    uint32_t it, it_end = 0;      // current item id; static mode: end of this workgroup's range
+    // dynamic mode, wave 0: pulls from the global cursor run two items ahead of the item being aligned.  The atomic
+    // is issued at the end of the step that starts an item and its result is published to seq[] at the top of the
+    // next step, so the returned value is only live across the barrier, not across the column loop.
+    uint32_t pending = 0, pub = 2;
+    bool pending_valid = false;
+    if (DYN) {
+        // the first two rounds are dealt like LPT deals them when all workgroups start together: item b to
+        // workgroup b, then the next gridDim.x items in reverse (the longest first item gets the shortest second
+        // one); everything after that comes from the cursor.  (Letting every workgroup pull its first two items
+        // from the cursor paired the two longest items on workgroup 0: -10 % on a small database.)
+        if (threadIdx.x == 0) {
+            const uint32_t g0 = blockIdx.x, g1 = 2 * gridDim.x - 1 - blockIdx.x;
+            seq[0] = g0 < p.n_items ? g0 : kNoItem;
+            seq[1] = g1 < p.n_items ? g1 : kNoItem;
+            *total_lds = g0 < p.n_items ? 0x3fffffff : 0;
+        }
+        __syncthreads();
+        it = seq[0];
+    } else {
+        __syncthreads();
+        it = p.wg_first[blockIdx.x];
+        it_end = p.wg_first[blockIdx.x + 1];
+        if (it >= it_end) it = kNoItem;
+    }
+    it = __builtin_amdgcn_readfirstlane(it);
+    int total = DYN ? 0x3fffffff : (int)p.wg_chunks[blockIdx.x];
 
     const V goe = Ops::splat(M == 2 ? -p.goe : p.goe), ge = Ops::splat(M == 2 ? -p.ge : p.ge);
-    const uint32_t it_end = p.wg_first[blockIdx.x + 1];
-    uint32_t it = p.wg_first[blockIdx.x];
-    const int total = (int)p.wg_chunks[blockIdx.x];
-    const int nsteps = FS ? total : total + W - 1;
     const unsigned char *my_prof = prof_lds + k * TP * 2;
 
     V H[T], E[T];
@@ -236,7 +255,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 #pragma unroll
     for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
 
-    uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, out_slot = 0;
+    uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, out_slot = 0, n = 0, next_it = kNoItem;
     uint64_t bnd_off = 0;
     const uint8_t *dbp = nullptr;
     uint32_t nwa = 0, nwb = 0;     // residues of the wave's next chunk, loaded one step ahead
@@ -245,18 +264,34 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 #ifdef SWIMM_STAMPS
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, sumA = 0, sumB = 0, sumC = 0, sumD = 0, nact = 0;
 #endif
-    for (int s = 0; s < nsteps; ++s) {
-        const int c = FS ? s : s - k;             // global chunk index of this wave in this step
+    for (int s = 0;; ++s) {
+        if (DYN) total = __builtin_amdgcn_readfirstlane(*(volatile int *)total_lds);   // same value in every wave: written before the last barrier
+        if (s >= total + W - 1) break;
+        if (DYN && (uint32_t)s > p.max_steps) {   // cannot happen (one workgroup can at most take every chunk of the list): never spin forever
+            if (threadIdx.x == 0) atomicOr(p.err, 4u);
+            break;
+        }
+        if (DYN && k == 0 && pending_valid) {
+            const uint32_t g = __builtin_amdgcn_readfirstlane(pending) + 2 * gridDim.x;   // the cursor starts behind the two dealt rounds
+            if (lane == 0) seq[pub & (kSeqRing - 1)] = g < p.n_items ? g : kNoItem;
+            ++pub;
+            pending_valid = false;
+        }
+        bool started = false;
+        const int c = s - k;                      // chunk index of this wave in the workgroup's sequence
         STAMP(tA);
-        if (c >= 0 && c < total && it < it_end) { // wave-uniform
+        if (c >= 0 && it != kNoItem) {            // wave-uniform
             if (cc == 0) {                        // first chunk of a new item: reset the DP state
-                const Item iv = p.items[it];
-                const GroupDesc g = p.groups[iv.group];
-                nch = g.ncols / C; dbp = g.db; seq0 = g.seq0;
-                half = iv.half; out_slot = iv.out_slot; bnd_off = iv.bnd_off;
+                // the item is the same for the whole wave: keep its descriptor in scalar registers
+                const Item iv = p.items[__builtin_amdgcn_readfirstlane(it)];
+                const GroupDesc g = p.groups[__builtin_amdgcn_readfirstlane(iv.group)];
+                nch = __builtin_amdgcn_readfirstlane(g.ncols / C); dbp = uniform_ptr(g.db); seq0 = __builtin_amdgcn_readfirstlane(g.seq0);
+                half = __builtin_amdgcn_readfirstlane(iv.half); out_slot = __builtin_amdgcn_readfirstlane(iv.out_slot);
+                bnd_off = uniform_u64(iv.bnd_off);
                 best = Ops::zero(); diag_top = Ops::zero();
 #pragma unroll
                 for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+                started = true;
             }
             // database residues of this chunk: 4 columns of the lane's sequence(s).  They were requested one
             // step ago (below): right after the barrier every wave would otherwise stall on this global load
@@ -278,9 +313,16 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 uint32_t ncc = cc + 1, nhalf = half;
                 have_next = true;
                 if (ncc == nch) {
-                    if (it + 1 < it_end && c + 1 < total) {
-                        const Item niv = p.items[it + 1];
-                        ndb = p.groups[niv.group].db; ncc = 0; nhalf = niv.half;
+                    // which item follows?  static: the next of the range; dynamic: the id wave 0 published in seq[]
+                    if (DYN) {
+                        next_it = __builtin_amdgcn_readfirstlane(seq[(n + 1) & (kSeqRing - 1)]);
+                        if (k == 0 && next_it == kNoItem && lane == 0) *total_lds = c + 1;   // this chunk is the last of the sequence
+                    } else {
+                        next_it = it + 1 < it_end ? it + 1 : kNoItem;
+                    }
+                    if (next_it != kNoItem) {
+                        const Item niv = p.items[next_it];
+                        ndb = uniform_ptr(p.groups[__builtin_amdgcn_readfirstlane(niv.group)].db); ncc = 0; nhalf = __builtin_amdgcn_readfirstlane(niv.half);
                     } else {
                         have_next = false;
                     }
@@ -305,17 +347,10 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                     for (int jj = 0; jj < C; ++jj) bin[jj] = p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane];
                 }
             } else {
-                if (FS && !wait_counter_above(prod + (k - 1), (uint32_t)c + 1)) { if (lane == 0) atomicOr(p.err, 1u); return; }
-                const uint2 *src = ring + (size_t)(((k - 1) * R + (c & (R - 1))) * C) * 64 + lane;
+                const uint2 *src = ring + (size_t)(((k - 1) * 2 + (c & 1)) * C) * 64 + lane;
 #pragma unroll
                 for (int jj = 0; jj < C; ++jj) bin[jj] = src[jj * 64];
-                if (FS) {   // the slot may be refilled once these reads have landed
-                    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-                    __hip_atomic_store(cons + k, (uint32_t)c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
             }
-            // my own output slot of this chunk must have been drained by the next wave (it held chunk c - R)
-            if (FS && k < W - 1 && c >= R && !wait_counter_above(cons + (k + 1), (uint32_t)(c - R) + 1)) { if (lane == 0) atomicOr(p.err, 2u); return; }
             STAMP(tB);
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) {
@@ -381,13 +416,12 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 }
                 // bottom boundary of this column: to the next wave through LDS, or (last wave, more passes) to HBM
                 const uint2 bout = make_uint2(Ops::bits(H[T - 1]), Ops::bits(F));
-                if (k < W - 1) ring[(size_t)((k * R + (c & (R - 1))) * C + jj) * 64 + lane] = bout;
+                if (k < W - 1) ring[(size_t)((k * 2 + (c & 1)) * C + jj) * 64 + lane] = bout;
                 else if (!p.last_pass) p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = bout;
                 // keep one column's lookups in flight at a time: without this fence the scheduler hoists
                 // all four columns' LDS reads and the kernel needs ~230 VGPRs (spills at 3 waves/SIMD)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (FS && k < W - 1) __hip_atomic_store(prod + k, (uint32_t)c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             STAMP(tC);
             if (++cc == nch) {   // item finished: every strip contributes its best (CPUsearch.c:670-676)
                 if (M == 2) {
@@ -402,67 +436,76 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                     atomicMax(p.out + (size_t)out_slot * 64 + lane, (int)Ops::bits(best));
                 }
                 cc = 0;
-                ++it;
+                ++n;
+                it = next_it;
             }
 #ifdef SWIMM_STAMPS
             STAMP(tD);
             sumA += tB - tA; sumB += tC - tB; sumC += tD - tC; nact++;
 #endif
         }
+        if (DYN && k == 0 && started) {          // one pull per item started keeps the look-ahead at two items
+            if (lane == 0) pending = atomicAdd(p.queue, 1u);
+            pending_valid = true;
+        }
 #ifdef SWIMM_STAMPS
-        { unsigned long long t0, t1; STAMP(t0); if (!FS) __syncthreads(); STAMP(t1); sumD += t1 - t0; }
+        { unsigned long long t0, t1; STAMP(t0); __syncthreads(); STAMP(t1); sumD += t1 - t0; }
 #else
-        if (!FS) __syncthreads();
+        __syncthreads();
 #endif
     }
 #ifdef SWIMM_STAMPS
     if (p.stamps && lane == 0) {
         atomicAdd(p.stamps + k * 8 + 0, sumA); atomicAdd(p.stamps + k * 8 + 1, sumB); atomicAdd(p.stamps + k * 8 + 2, sumC);
-        atomicAdd(p.stamps + k * 8 + 3, sumD); atomicAdd(p.stamps + k * 8 + 4, nact); atomicAdd(p.stamps + k * 8 + 5, (unsigned long long)nsteps);
+        atomicAdd(p.stamps + k * 8 + 3, sumD); atomicAdd(p.stamps + k * 8 + 4, nact); atomicAdd(p.stamps + k * 8 + 5, (unsigned long long)(total + W - 1));
     }
 #endif
 }
 
-template <int T, int M, bool FS>
+template <int T, int M, bool DYN>
 static hipError_t launch_one(int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
-    const size_t lds = pipe_lds_bytes(T, W, FS);
-    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, M, FS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = pipe_lds_bytes(T, W);
+    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, M, DYN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sw_pipe_kernel<T, M, FS>), dim3(n_wg), dim3(W * 64), lds, s, p);
+    hipLaunchKernelGGL((sw_pipe_kernel<T, M, DYN>), dim3(n_wg), dim3(W * 64), lds, s, p);
     return hipGetLastError();
 }
 
-template <int T, bool FS>
+template <int T, bool DYN>
 static hipError_t launch_mode(Mode mode, int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
-    if (mode == Mode::PK16) return launch_one<T, 0, FS>(W, n_wg, p, s);
-    if (mode == Mode::I32) return launch_one<T, 1, FS>(W, n_wg, p, s);
-    return launch_one<T, 2, FS>(W, n_wg, p, s);
+    if (mode == Mode::PK16) return launch_one<T, 0, DYN>(W, n_wg, p, s);
+    if (mode == Mode::I32) return launch_one<T, 1, DYN>(W, n_wg, p, s);
+    return launch_one<T, 2, DYN>(W, n_wg, p, s);
 }
 
-// Instantiations: T = 16 / 24 / 32 for every tier and both hand-over schemes; the f16 tier with barriers (the
-// default path) also has every other multiple of 4 from 8 to 36, so that the launch plan can give a query
-// W = 4, 8, 12 or 16 waves (an equal number on each of the CU's 4 SIMDs) with at most 3 padding rows per wave.
+// Instantiations: T = 16 / 24 / 32 for every tier; the f16 tier (the default path) also has every other multiple
+// of 4 from 8 to 36, so that the launch plan can give a query W = 4, 8, 12 or 16 waves (an equal number on each of
+// the CU's 4 SIMDs) with at most 3 padding rows per wave.
 #define SWIMM_EXTRA_T(X) X(8) X(12) X(20) X(28) X(36)
-bool pipe_has_variant(Mode mode, int T, bool flag_sync)
+bool pipe_has_variant(Mode mode, int T)
 {
     if (T == 16 || T == 24 || T == 32) return true;
-    if (mode != Mode::F16 || flag_sync) return false;
+    if (mode != Mode::F16) return false;
 #define X(t) if (T == t) return true;
     SWIMM_EXTRA_T(X)
 #undef X
     return false;
 }
 
-hipError_t launch_pipe(Mode mode, int T, int W, bool flag_sync, int n_wg, const PipeParams &p, hipStream_t s)
+hipError_t launch_pipe(Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
-    if (W < 1 || W > kMaxWaves || n_wg < 1 || !pipe_has_variant(mode, T, flag_sync)) return hipErrorInvalidValue;
+    if (W < 1 || W > kMaxWaves || n_wg < 1 || !pipe_has_variant(mode, T)) return hipErrorInvalidValue;
     if (T > 28 && W > 12) return hipErrorInvalidValue;    // __launch_bounds__ of those instantiations
-    if (flag_sync) {
+    const bool dyn = p.queue != nullptr;
+    if (dyn) {
         if (T == 32) return launch_mode<32, true>(mode, W, n_wg, p, s);
         if (T == 24) return launch_mode<24, true>(mode, W, n_wg, p, s);
         if (T == 16) return launch_mode<16, true>(mode, W, n_wg, p, s);
+#define X(t) if (T == t) return launch_one<t, 2, true>(W, n_wg, p, s);
+        SWIMM_EXTRA_T(X)
+#undef X
     } else {
         if (T == 32) return launch_mode<32, false>(mode, W, n_wg, p, s);
         if (T == 24) return launch_mode<24, false>(mode, W, n_wg, p, s);
@@ -477,20 +520,20 @@ hipError_t launch_pipe(Mode mode, int T, int W, bool flag_sync, int n_wg, const 
 template <int T>
 static const void *kernel_ptr(Mode mode)
 {
-    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0, false>;
-    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1, false>;
-    return (const void *)sw_pipe_kernel<T, 2, false>;
+    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0, true>;
+    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1, true>;
+    return (const void *)sw_pipe_kernel<T, 2, true>;
 }
 
 hipError_t pipe_kernel_attributes(Mode mode, int T, int *num_regs)
 {
     hipFuncAttributes a;
     const void *f = nullptr;
-    if (!pipe_has_variant(mode, T, false)) return hipErrorInvalidValue;
+    if (!pipe_has_variant(mode, T)) return hipErrorInvalidValue;
     if (T == 32) f = kernel_ptr<32>(mode);
     else if (T == 24) f = kernel_ptr<24>(mode);
     else if (T == 16) f = kernel_ptr<16>(mode);
-#define X(t) else if (T == t) f = (const void *)sw_pipe_kernel<t, 2, false>;
+#define X(t) else if (T == t) f = (const void *)sw_pipe_kernel<t, 2, true>;
     SWIMM_EXTRA_T(X)
 #undef X
     hipError_t e = hipFuncGetAttributes(&a, f);
@@ -546,7 +589,7 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // these waves carry the critical path (the longest alignments, or the re-runs a query is waiting for) and share
     // the SIMDs with bulk waves that run at priorities 3..0: keep them at the top
-    __builtin_amdgcn_s_setprio(3);
+    if (p.high_prio) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
     const int lane = threadIdx.x & 63;
     const int PS = prof_row_bytes(RP);
     const uint32_t pass = blockIdx.x / p.wg_per_pass;

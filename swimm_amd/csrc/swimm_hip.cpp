@@ -65,11 +65,13 @@ struct DevBuf {   // grow-only device scratch
 
 struct Plan {      // static partition of a work list over n_wg persistent workgroups
     int n_wg = 0;
-    DevBuf<Item> items;
+    DevBuf<Item> items;          // grouped by workgroup (static partition)
     DevBuf<uint32_t> wg_first, wg_chunks;
+    DevBuf<Item> queue_items;    // the same items sorted longest first (dynamic queue)
+    uint32_t n_items = 0;
     uint64_t bnd_cols = 0;   // columns the pass-boundary buffer must hold
     uint64_t max_wg_chunks = 0, total_chunks = 0;
-    void release() { items.release(); wg_first.release(); wg_chunks.release(); }
+    void release() { items.release(); wg_first.release(); wg_chunks.release(); queue_items.release(); }
 };
 
 // lane-systolic work list (long-sequence tail, int32 promotion): items sorted longest first, pulled
@@ -109,17 +111,23 @@ struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; };
 struct swimm_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;      // lane-systolic tail runs beside the bulk kernel
+    static constexpr int kTailStreams = 1;
+    hipStream_t tail_stream[kTailStreams] = {};   // lane-systolic tails run beside the bulk kernels, several queries' at once
+    hipEvent_t ev_tails[kTailStreams] = {};
     hipStream_t stream3 = nullptr;      // promotion re-runs
-    hipEvent_t ev_ready = nullptr, ev_tail = nullptr, ev_tail3 = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_tail3 = nullptr;
     std::vector<hipEvent_t> ev_query;   // [2q] bulk done, [2q+1] tail done
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cu = 0;
     // options
     int opt_T = 0, opt_maxW = 0, opt_W = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;   // 0 = chosen per query
+    std::map<int, double> imbalance_cache;   // n_wg -> LPT makespan / mean load of the resident database (bulk groups)
     int regs_cache[3][40] = {};            // VGPRs of sw_pipe_kernel<T, tier>, looked up once
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
-    int opt_sync = 0;                   // 0: one barrier per chunk (default, measured faster); 1: counter hand-over between neighbouring waves
+    int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
+    int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
+    DevBuf<uint32_t> d_queue;           // one cursor per pipeline launch of a search
+    uint32_t queue_next = 0;
     int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
     // queries (host copies; profiles are built per search because T/W may change)
     std::vector<int8_t> qcodes;
@@ -146,7 +154,7 @@ struct swimm_hip_ctx {
     DevBuf<unsigned long long> d_keys;
     DevBuf<uint32_t> d_err;             // pipeline watchdog word
     DevBuf<unsigned long long> d_stamps;   // diagnostic build only
-    LaneScratch tail_scratch;           // lane kernel on stream 2 (long-sequence tail)
+    LaneScratch tail_scratch[kTailStreams];   // one per tail stream (long-sequence tail)
     LaneScratch rerun_scratch;          // lane kernel on stream 3 (promotion re-runs)
     DevBuf<LaneItem> d_rerun_items;
     DevBuf<uint32_t> d_satlist;
@@ -163,6 +171,7 @@ void release_plans(swimm_hip_ctx *c)
 {
     for (auto &kv : c->plans) { kv.second.main.release(); kv.second.tail.release(); }
     c->plans.clear();
+    c->imbalance_cache.clear();
 }
 
 int regs_to_waves_per_simd(int regs)
@@ -178,11 +187,40 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
     int &regs = const_cast<swimm_hip_ctx *>(c)->regs_cache[(int)mode][T];
     if (regs == 0) HIP_TRY(pipe_kernel_attributes(mode, T, &regs));
     const int waves_cu = 4 * regs_to_waves_per_simd(regs);
-    const size_t lds = pipe_lds_bytes(T, W, c->opt_sync != 0);
+    const size_t lds = pipe_lds_bytes(T, W);
     int n = std::min(waves_cu / W, (int)(163840 / lds));
     if (c->opt_wgs_per_cu > 0) n = c->opt_wgs_per_cu;
     *out = std::max(1, n);
     return 0;
+}
+
+std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, int n_wg);
+
+// How evenly the bulk groups of the resident database spread over n_wg workgroups: makespan of the longest-first
+// greedy schedule (what the dynamic queue, and the static partition, produce) over the mean load.  1.00x for a
+// large database; a small one whose longest group is a sizeable part of a workgroup's share reaches 1.4 - 1.9
+// with 3 - 4 workgroups per CU, and then fewer, larger workgroups are the better launch shape.
+double plan_imbalance(swimm_hip_ctx *c, int n_wg)
+{
+    auto it = c->imbalance_cache.find(n_wg);
+    if (it != c->imbalance_cache.end()) return it->second;
+    const std::vector<uint8_t> is_tail = pick_tail(c, n_wg);
+    std::vector<uint32_t> cols;
+    uint64_t total = 0;
+    for (uint32_t g = 0; g < c->groups.size(); ++g)
+        if (!is_tail[g]) { cols.push_back(c->groups[g].ncols); total += c->groups[g].ncols; }
+    double r = 1.0;
+    if (!cols.empty() && total > 0) {
+        std::sort(cols.begin(), cols.end(), std::greater<uint32_t>());
+        const int n = std::max(1, std::min<int>(n_wg, (int)cols.size()));
+        std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> heap;
+        for (int w = 0; w < n; ++w) heap.push(0);
+        uint64_t mx = 0;
+        for (uint32_t x : cols) { uint64_t l = heap.top() + x; heap.pop(); heap.push(l); mx = std::max(mx, l); }
+        r = (double)mx / ((double)total / n_wg);   // fewer groups than workgroups: the idle ones count
+    }
+    c->imbalance_cache[n_wg] = r;
+    return r;
 }
 
 // Measured throughput (GCUPS of padded cells) of every launch shape of the f16-tier pipeline kernel: rows per wave
@@ -208,13 +246,13 @@ static const float kShapeGcups[8][16] = {
 // `room_for_lane_waves`: the database has a long-sequence tail that the lane kernel aligns on a second stream
 // while this kernel runs; only shapes that leave the 80 VGPRs per SIMD lane a lane-systolic wave needs are
 // admitted (e.g. 3 waves x 144, 4 x 104).
-int choose_plan(const swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, QueryPlan *out)
+int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, QueryPlan *out)
 {
     double best_cost = -1;
     for (int ti = 7; ti >= 0; --ti) {
         const int T = 8 + 4 * ti;
         if (c->opt_T && T != c->opt_T) continue;
-        if (!pipe_has_variant(mode, T, c->opt_sync != 0)) continue;
+        if (!pipe_has_variant(mode, T)) continue;
         int maxW = (T > 28) ? 12 : 16;        // __launch_bounds__ of the instantiations
         if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
         const int strips = std::max(1, (m + T - 1) / T);
@@ -227,7 +265,8 @@ int choose_plan(const swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_wav
                 const int alloc = (c->regs_cache[(int)mode][T] + 7) / 8 * 8;
                 if (alloc * ((per_cu * W + 3) / 4) > 512 - 80) continue;
             }
-            const double cost = (double)passes * T * W / kShapeGcups[ti][W - 1] * (passes > 1 ? (W >= 8 ? 1.005 : 1.17) : 1.0);
+            const double cost = (double)passes * T * W / kShapeGcups[ti][W - 1] * (passes > 1 ? (W >= 8 ? 1.005 : 1.17) : 1.0)
+                                * plan_imbalance(c, c->num_cu * per_cu);
             if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
                 best_cost = cost;
                 out->T = T; out->W = W; out->passes = passes; out->mpad = (uint32_t)(passes * W * T);
@@ -275,6 +314,15 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
     }
     first[n_wg] = (uint32_t)items.size();
     pl.n_wg = n_wg;
+    std::vector<Item> sorted; sorted.reserve(units.size());
+    for (uint32_t idx : order) {
+        const WorkUnit &u = units[idx];
+        Item it{}; it.group = u.group; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = u.bnd_off;
+        sorted.push_back(it);
+    }
+    pl.n_items = (uint32_t)sorted.size();
+    HIP_TRY(pl.queue_items.reserve(sorted.size()));
+    HIP_TRY(hipMemcpyAsync(pl.queue_items.p, sorted.data(), sorted.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(pl.items.reserve(items.size()));
     HIP_TRY(pl.wg_first.reserve(first.size()));
     HIP_TRY(pl.wg_chunks.reserve(chunks.size()));
@@ -319,7 +367,7 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, int n_wg)
     (void)n_wg;   // the yardstick is the load of a CU, however many workgroups share it
     for (uint32_t g : order) {
         const double mean = (double)rest / c->num_cu;
-        if ((double)c->groups[g].ncols <= 0.5 * mean) break;
+        if ((double)c->groups[g].ncols <= c->opt_tail_frac * 0.01 * mean) break;
         is_tail[g] = 1;
         rest -= c->groups[g].ncols;
     }
@@ -387,6 +435,13 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
         p.items = pl.items.p;
         p.wg_first = pl.wg_first.p;
         p.wg_chunks = pl.wg_chunks.p;
+        if (c->opt_dynamic) {
+            if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
+            p.items = pl.queue_items.p;
+            p.n_items = pl.n_items;
+            p.max_steps = (uint32_t)std::min<uint64_t>(pl.total_chunks + kMaxWaves + 1, 0x3ffffff0u);
+            p.queue = c->d_queue.p + c->queue_next++;
+        }
         p.r0 = (uint32_t)(pass * qp.W * qp.T);
         p.first_pass = pass == 0;
         p.last_pass = pass == qp.passes - 1;
@@ -397,7 +452,7 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
         p.stamps = c->d_stamps.p;
 #endif
         p.err = c->d_err.p;
-        HIP_TRY(launch_pipe(mode, qp.T, qp.W, c->opt_sync != 0, pl.n_wg, p, c->stream));
+        HIP_TRY(launch_pipe(mode, qp.T, qp.W, pl.n_wg, p, c->stream));
 #ifdef SWIMM_STAMPS
         {
             unsigned long long h[16 * 8];
@@ -447,6 +502,7 @@ int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, con
     p.goe = c->open_gap + c->extend_gap;
     p.ge = c->extend_gap;
     p.err = c->d_err.p;
+    p.high_prio = getenv("SWIMM_HIP_TAIL_PRIO") ? atoi(getenv("SWIMM_HIP_TAIL_PRIO")) : (&sc == &c->rerun_scratch ? 1 : 1);
     HIP_TRY(hipMemsetAsync(sc.queue.p, 0, passes * sizeof(uint32_t), st));
     if (passes > 1) HIP_TRY(hipMemsetAsync(sc.prog.p, 0, need_prog * sizeof(uint32_t), st));
     HIP_TRY(launch_lane(mode, passes * per_pass, p, st));
@@ -498,7 +554,8 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     if (c->opt_tail_mode != 2 && main_mode != Mode::I32) {
         uint32_t longest = 0;
         for (const GroupDesc &g : c->groups) longest = std::max(longest, g.ncols);
-        lane_room = c->opt_tail_mode == 1 || (double)longest > 0.5 * (double)c->total_cols / c->num_cu;
+        lane_room = c->opt_tail_mode == 1 || (double)longest > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
+        if (getenv("SWIMM_HIP_NO_LANE_ROOM")) lane_room = false;   // tuning experiment
     }
     std::vector<QueryPlan> qps(qn);
     size_t prof_elems = 0;
@@ -522,6 +579,13 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     c->last_plans = qps;
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    {   // one zeroed queue cursor per pipeline launch of this search
+        size_t launches = 16;
+        for (uint32_t q = 0; q < qn; ++q) launches += (size_t)qps[q].passes;
+        HIP_TRY(c->d_queue.reserve(launches));
+        HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launches * sizeof(uint32_t), c->stream));
+        c->queue_next = 0;
+    }
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
     HIP_TRY(hipMemsetAsync(c->d_scores.p, 0, (size_t)qn * S * sizeof(int32_t), c->stream));
 
@@ -542,7 +606,8 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             max_passes = std::max(max_passes, (int)((c->qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
         }
         HIP_TRY(c->d_bnd.reserve(need_bnd));
-        if (reserve_lane_scratch(c->tail_scratch, tail_cols, tail_items, max_passes)) return 1;
+        for (LaneScratch &ts : c->tail_scratch)
+            if (reserve_lane_scratch(ts, tail_cols, tail_items, max_passes)) return 1;
         if (reserve_lane_scratch(c->rerun_scratch, (size_t)1 << 22, 4096, max_passes)) return 1;
         HIP_TRY(c->d_satlist.reserve((size_t)(1u << 16) + 1));
         HIP_TRY(c->d_rerun_items.reserve(4096));
@@ -551,7 +616,7 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     HIP_TRY(hipMemsetAsync(c->d_err.p, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
-    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
+    for (hipStream_t ts : c->tail_stream) HIP_TRY(hipStreamWaitEvent(ts, c->ev_ready, 0));
     HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
     while (c->ev_query.size() < 2 * (size_t)qn) {
         hipEvent_t e;
@@ -571,10 +636,14 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             fprintf(stderr, "swimm_hip: query %u: %d workgroups (%d per CU), %u tail items, main %s\n", q, dp->main.n_wg, per_cu, dp->tail.n, dp->have_main ? "yes" : "no");
         // the long-sequence tail (a few long serial chains, one wave each) runs on its own stream beside the
         // bulk kernel: 3 bulk waves (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly
-        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row, c->stream2, c->tail_scratch)) return 1;
+        // Each tail is a handful of long serial chains, bound by latency, not by issue slots: the tails of several
+        // queries run at once (round-robin over the tail streams), so their waves -- which run at top priority and
+        // slow down the barrier-coupled bulk workgroups they share a CU with -- are in flight for a short time only.
+        const int tsi = (int)(k % swimm_hip_ctx::kTailStreams);
+        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row, c->tail_stream[tsi], c->tail_scratch[tsi])) return 1;
         if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row)) return 1;
         HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
-        HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->stream2));
+        HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->tail_stream[tsi]));
     }
     // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
     // f16 results >= 2048 are re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; each
@@ -662,8 +731,10 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             if (rerun(q, Mode::I32, items)) return 1;
         }
     }
-    HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
+    for (int i = 0; i < swimm_hip_ctx::kTailStreams; ++i) {
+        HIP_TRY(hipEventRecord(c->ev_tails[i], c->tail_stream[i]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tails[i], 0));
+    }
     HIP_TRY(hipEventRecord(c->ev_tail3, c->stream3));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail3, 0));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -709,11 +780,13 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     swimm_hip_ctx *c = new swimm_hip_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+    bool tails_ok = true;
+    for (int i = 0; i < swimm_hip_ctx::kTailStreams; ++i)
+        tails_ok = tails_ok && hipStreamCreate(&c->tail_stream[i]) == hipSuccess && hipEventCreateWithFlags(&c->ev_tails[i], hipEventDisableTiming) == hipSuccess;
+    if (!tails_ok || hipStreamCreate(&c->stream) != hipSuccess ||
         hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return fail("swimm_hip_create: stream/event creation failed");
     }
@@ -727,14 +800,14 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
     c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
-    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
+    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); for (LaneScratch &ts : c->tail_scratch) ts.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    for (hipEvent_t e : c->ev_tails) if (e) (void)hipEventDestroy(e);
     if (c->ev_tail3) (void)hipEventDestroy(c->ev_tail3);
     for (hipEvent_t e : c->ev_query) (void)hipEventDestroy(e);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (hipStream_t ts : c->tail_stream) if (ts) (void)hipStreamDestroy(ts);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -977,8 +1050,12 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         c->opt_maxW = value;
     } else if (!strcmp(key, "force_i32")) {
         c->opt_force_i32 = value != 0;
-    } else if (!strcmp(key, "sync")) {
-        c->opt_sync = value != 0;
+    } else if (!strcmp(key, "tail_frac")) {
+        if (value < 1 || value > 1000) return fail("tail_frac must be 1..1000 (percent of a CU's mean load)");
+        c->opt_tail_frac = value;
+        release_plans(c);
+    } else if (!strcmp(key, "dynamic")) {
+        c->opt_dynamic = value != 0;
     } else if (!strcmp(key, "f16")) {
         c->opt_f16 = value != 0;
     } else if (!strcmp(key, "tail_mode")) {

@@ -46,7 +46,7 @@ def test_golden_all_cases(searcher, gin, golden):
 @pytest.mark.parametrize("opts", [{"force_i32": 1}, {"rows_per_wave": 16}, {"max_waves": 1}, {"max_waves": 5, "wgs_per_cu": 1},
                                   {"tail_mode": 1}, {"tail_mode": 2}, {"tail_mode": 1, "rows_per_wave": 16}, {"rows_per_wave": 24},
                                   {"f16": 0}, {"f16": 0, "tail_mode": 2}, {"f16": 1, "rows_per_wave": 24, "tail_mode": 2},
-                                  {"sync": 1}, {"sync": 1, "tail_mode": 2, "f16": 0}, {"sync": 1, "tail_mode": 2, "max_waves": 3},
+                                  {"dynamic": 0}, {"dynamic": 0, "tail_mode": 2, "f16": 0}, {"dynamic": 0, "tail_mode": 2, "max_waves": 3},
                                   {"rows_per_wave": 8}, {"rows_per_wave": 12, "tail_mode": 2}, {"rows_per_wave": 20}, {"rows_per_wave": 28, "waves": 4},
                                   {"rows_per_wave": 36}, {"rows_per_wave": 36, "waves": 3, "tail_mode": 2}, {"rows_per_wave": 20, "waves": 7}])
 def test_golden_kernel_variants(gin, golden, opts):

@@ -23,9 +23,11 @@ from swimm_amd import hip_backend, host, submat, synth  # noqa: E402
 
 CFG = {
     "c2": dict(lengths="c2", queries=[3], matrix="blosum62"),
+    "c2long": dict(lengths="c2", queries=[19], matrix="blosum62"),
     "c3": dict(lengths="c3", queries=list(range(20)), matrix="blosum50"),
     "c4": dict(lengths="c4", queries=[19], matrix="blosum62"),
     "c5": dict(lengths="c5", queries=list(range(20)), matrix="pam250"),
+    "c3clip": dict(lengths="c3", queries=list(range(20)), matrix="blosum50", clip=3000),   # c3 without its long-sequence tail
 }
 
 
@@ -33,6 +35,8 @@ def build(cfg, scale, seed):
     qs_all = synth.make_queries(seed)
     qs = [qs_all[i] for i in cfg["queries"]]
     base = synth.config_lengths(cfg["lengths"], scale)
+    if cfg.get("clip"):
+        base = np.minimum(base, cfg["clip"])
     planted = synth.planted_homologs(seed, qs)
     lens = np.concatenate([base, np.array([len(s) for _, s in planted], dtype=np.int64)])
     order = np.argsort(lens, kind="stable")
@@ -73,7 +77,7 @@ def main():
     if args.only:
         cfg["queries"] = [cfg["queries"][int(i)] for i in args.only.split(",")]
     t0 = time.time()
-    L, codes, offs, a, m, disp = build(cfg, args.scale, {"c2": 2, "c3": 3, "c4": 5, "c5": 5}[args.config])
+    L, codes, offs, a, m, disp = build(cfg, args.scale, {"c2": 2, "c2long": 2, "c3": 3, "c4": 5, "c5": 5, "c3clip": 3}[args.config])
     chunks = host.Chunks(L, codes, 128, 96 << 20)
     residues = int(L.astype(np.int64).sum())
     print(f"# {args.config} scale {args.scale}: {len(L)} sequences, {residues} residues, {len(m)} queries (sum {int(m.sum())} aa), "

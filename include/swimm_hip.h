@@ -98,11 +98,18 @@ int swimm_hip_last_stats(swimm_hip_ctx *ctx, double *kernel_ms, uint64_t *cells,
  * rows of the query held per wavefront, wavefronts per workgroup, passes over the database. */
 int swimm_hip_last_plan(swimm_hip_ctx *ctx, uint32_t q, int *rows_per_wave, int *waves, int *passes);
 
-/* Tuning knobs (optional).  key: "rows_per_wave" (0 = chosen per query, 16/24/32), "max_waves" (1..16), "force_i32" (0/1),
- * "wgs_per_cu" (0 = auto), "tail_mode" (0 = auto: unusually long groups go through the lane-systolic
- * kernel, 1 = every group, 2 = none), "f16" (1 = default: packed binary16 first tier, exact below 2048, with
- * int16 and int32 re-runs above; 0 = packed int16 first tier), "sync" (0 = default: one workgroup barrier per chunk; 1 = neighbouring waves
- * hand chunks over through LDS counters -- measured 1.5 % slower, kept for experiments).  Unknown key -> error. */
+/* Tuning knobs (optional).  key:
+ *   "rows_per_wave"  0 = launch shape chosen per query (default); 8, 12, ... 36 forces the rows per wavefront
+ *                    (the int16 / int32 first tiers have 16, 24, 32 only)
+ *   "waves"          0 = chosen per query; 1..16 forces the wavefronts per workgroup;  "max_waves" caps them
+ *   "wgs_per_cu"     0 = by occupancy
+ *   "f16"            1 = default: packed binary16 first tier, exact below 2048, int16 and int32 re-runs above;
+ *                    0 = packed int16 first tier
+ *   "force_i32"      1 = everything in int32 (one sequence per lane)
+ *   "tail_mode"      0 = auto: unusually long groups go through the lane-systolic kernel, 1 = every group, 2 = none
+ *   "tail_frac"      a group is "unusually long" above this percentage of a CU's mean load (default 50)
+ *   "dynamic"        1 = default: workgroups pull groups from a global queue; 0 = static longest-first partition
+ * Unknown key -> error. */
 int swimm_hip_set_option(swimm_hip_ctx *ctx, const char *key, int value);
 
 /* Whole-call drop-in with the argument list of mic_search_knc_ap_multiple_chunks

@@ -216,13 +216,17 @@ def main():
         m_real = len(q)
         ms_per_step = elapsed / args.steps * 1e3
         gcups = m_real * total_residues * args.steps / elapsed / 1e9
-        # dominant kernel: sw_pipe_kernel<32,true>; one launch per step for this query (single pass)
+        # dominant kernel: sw_pipe_kernel<T, f16 tier, dynamic queue>; one launch per step for this query (single pass)
         k_ms = float(np.mean(kernel_ms))
         launches = max(1, stats["launches"])
+        plan_now = searcher.last_plan(0)
         cells_real = m_real * float(shard["residues"])
-        # algorithmic HBM bytes of one launch: database residues read once per pass (1/m B per cell);
-        # the strip boundary stays in LDS for a single-pass query (4*w/T term = 0)
-        alg_bytes = float(padded_bytes) + 8.0 * shard["n"]
+        # algorithmic HBM bytes of one launch (= one pass): the tiled database residues are read once per pass
+        # (1/m B per cell per pass) and the scores are updated (8 B per sequence); between two passes the strip
+        # boundary (H and F, 2 B each, per sequence and column = 4x the tiled residue bytes) is written once and
+        # read once -- SURVEY 8(d): 4*w/T_eff with w = 2 and T_eff = rows per pass; a one-pass query has no such term
+        passes = max(1, plan_now["passes"])
+        alg_bytes = float(padded_bytes) * (1.0 + 8.0 * (passes - 1) / passes) + 8.0 * shard["n"]
         achieved = alg_bytes / (k_ms / launches * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -248,9 +252,9 @@ def main():
                        "topr_exchange": "none" if world == 1 else ("rccl all_gather" if rccl is not None else "gloo all_gather")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": f"swimm::sw_pipe_kernel<{T}, 2, false>", "kernel_ms": round(k_ms / launches, 4),
+                         "kernel": f"swimm::sw_pipe_kernel<{T}, 2, true>", "kernel_ms": round(k_ms / launches, 4),
                          "alg_bytes_per_launch": alg_bytes,
-                         "note": "VALU-bound kernel: see valu_roofline; HBM carries only the DB residues (1/m B per cell)"},
+                         "note": "VALU-bound kernel: see valu_roofline; HBM carries the DB residues once per pass and the strip boundary between passes"},
             "valu_roofline": {"achieved": round(ginstr, 1), "peak": round(VALU_PEAK_GINSTR, 1), "unit": "G wave-instr/s",
                               "frac": round(ginstr / VALU_PEAK_GINSTR, 4), "kernel_only_gcups": round(kernel_gcups, 2),
                               "padded_cells": cells_padded, "instr_per_wave_column": T * INSTR_PER_ROW + INSTR_PER_COLUMN},

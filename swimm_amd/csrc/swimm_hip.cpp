@@ -228,14 +228,14 @@ double plan_imbalance(swimm_hip_ctx *c, int n_wg)
 // (tools/plan_sweep.py on one MI355X, profiles/r01_plan_sweep.txt).  W = 4, 8, 12, 16 put the same number of waves
 // on each of the CU's 4 SIMDs; any other W runs like the next multiple of 4 (2 x 6 waves behave like 4+4+2+2).
 static const float kShapeGcups[8][16] = {
-    {2345, 4100, 5262, 6672, 5488, 6244, 6419, 7310, 6545, 4730, 6576, 7028, 6468, 6462, 5550, 7228},     // T=8
-    {2934, 4856, 6092, 6866, 5743, 6710, 6660, 7613, 6173, 6458, 6933, 7469, 5702, 6102, 6566, 6991},     // T=12
-    {3321, 5424, 6321, 7340, 6218, 4582, 6754, 7699, 5293, 5855, 6448, 6988, 6076, 6504, 6951, 7389},     // T=16
-    {3532, 5822, 6498, 7553, 4236, 6184, 6711, 7728, 5494, 6125, 6691, 7314, 6128, 6730, 7175, 7666},     // T=20
-    {3821, 6222, 6574, 7792, 4576, 5977, 6865, 7812, 5701, 6334, 6904, 7534, 6354, 6902, 7367, 7858},     // T=24
-    {3894, 6324, 6576, 7843, 5170, 6048, 6996, 7951, 5826, 6462, 7081, 7721, 6539, 7028, 7514, 8031},     // T=28
-    {4068, 6751, 6763, 7739, 4596, 5486, 6402, 7284, 5892, 6530, 7171, 7801, 0, 0, 0, 0},                 // T=32
-    {4187, 6880, 6402, 7758, 4700, 5610, 6419, 7482, 6004, 6670, 6946, 7970, 0, 0, 0, 0},                 // T=36
+    {2142, 3826, 4468, 5585, 5950, 6378, 6876, 7489, 6962, 5951, 6690, 7265, 6738, 6696, 5827, 7542},     // T=8
+    {2719, 4343, 5328, 6655, 6497, 6901, 7216, 8026, 7331, 6558, 7291, 7857, 7241, 7140, 7606, 8042},     // T=12
+    {3158, 4664, 5951, 7588, 6471, 5452, 7046, 8023, 5258, 5864, 6434, 6983, 6010, 6475, 6929, 7379},     // T=16
+    {3390, 4995, 6347, 7702, 5490, 5553, 7165, 8126, 5502, 6106, 6696, 7307, 6106, 6716, 7184, 7654},     // T=20
+    {3640, 5220, 6748, 7980, 5506, 6260, 7252, 8122, 5633, 6283, 6904, 7526, 6337, 6889, 7359, 7846},     // T=24
+    {3832, 5521, 6751, 8074, 6148, 6257, 7257, 8253, 5799, 6429, 7072, 7704, 6514, 7018, 7507, 8002},     // T=28
+    {3627, 5778, 6902, 8352, 4583, 5476, 6365, 7267, 5889, 6527, 7168, 7812, 0, 0, 0, 0},                 // T=32
+    {3809, 5958, 6024, 8419, 4664, 5594, 6460, 7449, 5960, 6630, 7030, 7934, 0, 0, 0, 0},                 // T=36
 };
 
 // Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the shape with the lowest

@@ -67,7 +67,8 @@ struct Plan {      // static partition of a work list over n_wg persistent workg
     int n_wg = 0;
     DevBuf<Item> items;          // grouped by workgroup (static partition)
     DevBuf<uint32_t> wg_first, wg_chunks;
-    DevBuf<Item> queue_items;    // the same items sorted longest first (dynamic queue)
+    DevBuf<Item> queue_items;    // the same items sorted longest first (dynamic queue); bnd_off = columns before the item in this order
+    std::vector<uint32_t> queue_cols;   // their column counts (host copy, for cutting the list into boundary-buffer segments)
     uint32_t n_items = 0;
     uint64_t bnd_cols = 0;   // columns the pass-boundary buffer must hold
     uint64_t max_wg_chunks = 0, total_chunks = 0;
@@ -124,6 +125,8 @@ struct swimm_hip_ctx {
     std::map<int, double> imbalance_cache;   // n_wg -> LPT makespan / mean load of the resident database (bulk groups)
     int regs_cache[3][40] = {};            // VGPRs of sw_pipe_kernel<T, tier>, looked up once
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
+    int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
+    int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
     int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
     int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
     DevBuf<uint32_t> d_queue;           // one cursor per pipeline launch of a search
@@ -315,10 +318,14 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
     first[n_wg] = (uint32_t)items.size();
     pl.n_wg = n_wg;
     std::vector<Item> sorted; sorted.reserve(units.size());
+    pl.queue_cols.clear();
+    uint64_t before = 0;
     for (uint32_t idx : order) {
         const WorkUnit &u = units[idx];
-        Item it{}; it.group = u.group; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = u.bnd_off;
+        Item it{}; it.group = u.group; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = before;
+        before += u.ncols;
         sorted.push_back(it);
+        pl.queue_cols.push_back(u.ncols);
     }
     pl.n_items = (uint32_t)sorted.size();
     HIP_TRY(pl.queue_items.reserve(sorted.size()));
@@ -426,51 +433,84 @@ void fill_common(const swimm_hip_ctx *c, const QueryPlan &qp, PipeParams &p)
     p.ge = c->extend_gap;
 }
 
+// columns of boundary rows (64 lanes x 8 B each) the pass-boundary buffer may hold
+static uint64_t bnd_budget_cols(const swimm_hip_ctx *c) { return ((uint64_t)c->opt_bnd_mib << 20) / (64 * sizeof(uint2)); }
+
+// Cuts the longest-first item list into runs whose boundary rows fit the budget (always at least one item).  A
+// multi-pass query takes every run through all its passes before the next run starts, so the buffer holds one
+// run's columns only: 4x the run's tiled residue bytes instead of 4x the whole database.
+static void boundary_segments(const swimm_hip_ctx *c, const Plan &pl, std::vector<std::pair<uint32_t, uint32_t>> &segs, uint64_t *max_cols)
+{
+    const uint64_t budget = bnd_budget_cols(c);
+    segs.clear();
+    uint64_t mx = 0, cur = 0;
+    uint32_t first = 0;
+    for (uint32_t i = 0; i < pl.n_items; ++i) {
+        if (i > first && cur + pl.queue_cols[i] > budget) { segs.push_back({first, i}); mx = std::max(mx, cur); first = i; cur = 0; }
+        cur += pl.queue_cols[i];
+    }
+    if (pl.n_items > first) { segs.push_back({first, pl.n_items}); mx = std::max(mx, cur); }
+    if (max_cols) *max_cols = mx;
+}
+
 int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row)
 {
-    if (qp.passes > 1) HIP_TRY(c->d_bnd.reserve(pl.bnd_cols * 64));
-    for (int pass = 0; pass < qp.passes; ++pass) {
-        PipeParams p{};
-        fill_common(c, qp, p);
-        p.items = pl.items.p;
-        p.wg_first = pl.wg_first.p;
-        p.wg_chunks = pl.wg_chunks.p;
+    std::vector<std::pair<uint32_t, uint32_t>> segs;
+    uint64_t seg_cols = pl.bnd_cols;
+    if (c->opt_dynamic && qp.passes > 1) boundary_segments(c, pl, segs, &seg_cols);
+    else segs.push_back({0u, pl.n_items});
+    if (qp.passes > 1) HIP_TRY(c->d_bnd.reserve(seg_cols * 64));
+    for (const auto &sg : segs) {
+        uint64_t col0 = 0, seg_chunks = pl.total_chunks;
         if (c->opt_dynamic) {
-            if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
-            p.items = pl.queue_items.p;
-            p.n_items = pl.n_items;
-            p.max_steps = (uint32_t)std::min<uint64_t>(pl.total_chunks + kMaxWaves + 1, 0x3ffffff0u);
-            p.queue = c->d_queue.p + c->queue_next++;
+            col0 = 0; seg_chunks = 0;
+            for (uint32_t i = 0; i < sg.first; ++i) col0 += pl.queue_cols[i];
+            for (uint32_t i = sg.first; i < sg.second; ++i) seg_chunks += pl.queue_cols[i] / kChunkCols;
         }
-        p.r0 = (uint32_t)(pass * qp.W * qp.T);
-        p.first_pass = pass == 0;
-        p.last_pass = pass == qp.passes - 1;
-        p.out = out_row;
+        const int n_wg = c->opt_dynamic ? (int)std::min<uint32_t>((uint32_t)pl.n_wg, sg.second - sg.first) : pl.n_wg;
+        for (int pass = 0; pass < qp.passes; ++pass) {
+            PipeParams p{};
+            fill_common(c, qp, p);
+            p.items = pl.items.p;
+            p.wg_first = pl.wg_first.p;
+            p.wg_chunks = pl.wg_chunks.p;
+            if (c->opt_dynamic) {
+                if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
+                p.items = pl.queue_items.p + sg.first;
+                p.n_items = sg.second - sg.first;
+                p.max_steps = (uint32_t)std::min<uint64_t>(seg_chunks + kMaxWaves + 1, 0x3ffffff0u);
+                p.queue = c->d_queue.p + c->queue_next++;
+                p.bnd = c->d_bnd.p - col0 * 64;      // the items' offsets count columns from the start of the whole list
+            }
+            p.r0 = (uint32_t)(pass * qp.W * qp.T);
+            p.first_pass = pass == 0;
+            p.last_pass = pass == qp.passes - 1;
+            p.out = out_row;
 #ifdef SWIMM_STAMPS
-        HIP_TRY(c->d_stamps.reserve(16 * 8));
-        HIP_TRY(hipMemsetAsync(c->d_stamps.p, 0, 16 * 8 * sizeof(unsigned long long), c->stream));
-        p.stamps = c->d_stamps.p;
+            HIP_TRY(c->d_stamps.reserve(16 * 8));
+            HIP_TRY(hipMemsetAsync(c->d_stamps.p, 0, 16 * 8 * sizeof(unsigned long long), c->stream));
+            p.stamps = c->d_stamps.p;
 #endif
-        p.err = c->d_err.p;
-        HIP_TRY(launch_pipe(mode, qp.T, qp.W, pl.n_wg, p, c->stream));
+            p.err = c->d_err.p;
+            HIP_TRY(launch_pipe(mode, qp.T, qp.W, n_wg, p, c->stream));
 #ifdef SWIMM_STAMPS
-        {
-            unsigned long long h[16 * 8];
-            HIP_TRY(hipMemcpyAsync(h, c->d_stamps.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            for (int w = 0; w < qp.W; ++w)
-                fprintf(stderr, "stamps wave %2d: load/wait %8.0f  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active of %llu steps per wg)\n",
-                        w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4],
-                        (double)h[w * 8 + 3] / h[w * 8 + 4], h[w * 8 + 4] / pl.n_wg, h[w * 8 + 5] / pl.n_wg);
+            {
+                unsigned long long h[16 * 8];
+                HIP_TRY(hipMemcpyAsync(h, c->d_stamps.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                for (int w = 0; w < qp.W; ++w)
+                    fprintf(stderr, "stamps wave %2d: load/wait %8.0f  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active of %llu steps per wg)\n",
+                            w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4],
+                            (double)h[w * 8 + 3] / h[w * 8 + 4], h[w * 8 + 4] / pl.n_wg, h[w * 8 + 5] / pl.n_wg);
+            }
+#endif
+            c->launches++;
+            c->cells += seg_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * (mode == Mode::I32 ? 64 : 128);
         }
-#endif
-        c->launches++;
-        c->cells += pl.total_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * (mode == Mode::I32 ? 64 : 128);
     }
     return 0;
 }
 
-// the lane-systolic kernel over one work list for one query: ONE launch, all passes chained per item
 int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row, hipStream_t st,
                     LaneScratch &sc)
 {
@@ -533,17 +573,20 @@ int upload_groups(swimm_hip_ctx *c)
     return 0;
 }
 
-// device part of a search: leaves exact scores in d_scores[q * S + local_slot]
-int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
+// device part of a search for the queries [qb, qe) (ascending-length order of set_queries): leaves exact scores in
+// d_scores[(q - qb) * S + local_slot].  The callers walk the query list in batches whose score rows fit
+// kScoreBudgetBytes of HBM.
+int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_out)
 {
     if (!c->have_queries) return fail("swimm_hip_search: no queries set");
     if (c->groups.empty()) return fail("swimm_hip_search: no database chunk resident");
     HIP_TRY(hipSetDevice(c->device));
     if (upload_groups(c)) return 1;
-    const uint32_t qn = (uint32_t)c->qm.size();
+    const uint32_t qn = qe - qb;
+    const uint16_t *qm = c->qm.data() + qb;
+    const uint32_t *qdisp = c->qdisp.data() + qb;
     const uint64_t S = (uint64_t)c->groups.size() * kGroupSeqs;
     *slots_out = S;
-    c->kernel_ms = 0; c->cells = 0; c->promoted = 0; c->promoted16 = 0; c->launches = 0;
 
     // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
@@ -560,32 +603,26 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     std::vector<QueryPlan> qps(qn);
     size_t prof_elems = 0;
     for (uint32_t q = 0; q < qn; ++q) {
-        if (choose_plan(c, main_mode, c->qm[q], lane_room, &qps[q])) return 1;
+        if (choose_plan(c, main_mode, qm[q], lane_room, &qps[q])) return 1;
         if (getenv("SWIMM_HIP_DEBUG"))
-            fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, c->qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
-        const uint32_t lane_rows = (uint32_t)((c->qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
+            fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
+        const uint32_t lane_rows = (uint32_t)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
         qps[q].mpad = std::max(qps[q].mpad, lane_rows);
         qps[q].prof_off = prof_elems;
         prof_elems += (size_t)kCodes * qps[q].mpad;
     }
     std::vector<int16_t> prof(prof_elems, 0);
     for (uint32_t q = 0; q < qn; ++q) {
-        const int8_t *qa = c->qcodes.data() + c->qdisp[q];
+        const int8_t *qa = c->qcodes.data() + qdisp[q];
         for (int d = 0; d < kCodes; ++d) {
             int16_t *row = prof.data() + qps[q].prof_off + (size_t)d * qps[q].mpad;
-            for (uint32_t r = 0; r < c->qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + d];
+            for (uint32_t r = 0; r < qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + d];
         }
     }
-    c->last_plans = qps;
+    c->last_plans.resize(c->qm.size());
+    for (uint32_t q = 0; q < qn; ++q) c->last_plans[qb + q] = qps[q];
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-    {   // one zeroed queue cursor per pipeline launch of this search
-        size_t launches = 16;
-        for (uint32_t q = 0; q < qn; ++q) launches += (size_t)qps[q].passes;
-        HIP_TRY(c->d_queue.reserve(launches));
-        HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launches * sizeof(uint32_t), c->stream));
-        c->queue_next = 0;
-    }
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
     HIP_TRY(hipMemsetAsync(c->d_scores.p, 0, (size_t)qn * S * sizeof(int32_t), c->stream));
 
@@ -593,19 +630,32 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     // multi-stream phase would free memory a kernel in flight still uses
     {
         uint64_t need_bnd = 0;
-        size_t tail_cols = 0, tail_items = 0;
+        size_t tail_cols = 0, tail_items = 0, launch_total = 16;
         int max_passes = 1;
         for (uint32_t q = 0; q < qn; ++q) {
             int per_cu = 1;
             if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
             DbPlan *dp = nullptr;
             if (get_db_plan(c, main_mode, c->num_cu * per_cu, &dp)) return 1;
-            if (qps[q].passes > 1 && dp->have_main) need_bnd = std::max<uint64_t>(need_bnd, dp->main.bnd_cols * 64);
+            size_t nsegs = 1;
+            if (qps[q].passes > 1 && dp->have_main) {
+                uint64_t cols = dp->main.bnd_cols;
+                if (c->opt_dynamic) {
+                    std::vector<std::pair<uint32_t, uint32_t>> segs;
+                    boundary_segments(c, dp->main, segs, &cols);
+                    nsegs = segs.size();
+                }
+                need_bnd = std::max<uint64_t>(need_bnd, cols * 64);
+            }
+            launch_total += (size_t)qps[q].passes * nsegs;
             tail_cols = std::max<size_t>(tail_cols, dp->tail.cols);
             tail_items = std::max<size_t>(tail_items, dp->tail.n);
-            max_passes = std::max(max_passes, (int)((c->qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
+            max_passes = std::max(max_passes, (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
         }
         HIP_TRY(c->d_bnd.reserve(need_bnd));
+        HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
+        HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
+        c->queue_next = 0;
         for (LaneScratch &ts : c->tail_scratch)
             if (reserve_lane_scratch(ts, tail_cols, tail_items, max_passes)) return 1;
         if (reserve_lane_scratch(c->rerun_scratch, (size_t)1 << 22, 4096, max_passes)) return 1;
@@ -636,11 +686,10 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             fprintf(stderr, "swimm_hip: query %u: %d workgroups (%d per CU), %u tail items, main %s\n", q, dp->main.n_wg, per_cu, dp->tail.n, dp->have_main ? "yes" : "no");
         // the long-sequence tail (a few long serial chains, one wave each) runs on its own stream beside the
         // bulk kernel: 3 bulk waves (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly
-        // Each tail is a handful of long serial chains, bound by latency, not by issue slots: the tails of several
-        // queries run at once (round-robin over the tail streams), so their waves -- which run at top priority and
-        // slow down the barrier-coupled bulk workgroups they share a CU with -- are in flight for a short time only.
+        // (one tail launch at a time: several at once were measured 5 % slower on c3, and the chained passes of
+        // concurrent launches could wait for each other's workgroups)
         const int tsi = (int)(k % swimm_hip_ctx::kTailStreams);
-        if (run_lane_passes(c, Mode::PK16, qps[q], c->qm[q], dp->tail, row, c->tail_stream[tsi], c->tail_scratch[tsi])) return 1;
+        if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, c->tail_stream[tsi], c->tail_scratch[tsi])) return 1;
         if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row)) return 1;
         HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
         HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->tail_stream[tsi]));
@@ -673,7 +722,7 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             std::stable_sort(items.begin(), items.end(), [](const LaneItem &a, const LaneItem &b) { return a.ncols > b.ncols; });
             uint64_t cols = 0;
             for (LaneItem &it : items) { it.bnd_off = (uint32_t)cols; cols += it.ncols; }
-            const int rpasses = (int)((c->qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows));
+            const int rpasses = (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows));
             if (items.size() > c->d_rerun_items.cap || (rpasses > 1 && cols + 64 > c->rerun_scratch.bnd[0].cap) ||
                 items.size() * (size_t)rpasses > c->rerun_scratch.prog.cap) {
                 // growing a buffer frees the old one, which waits for the whole device: rare (first big batch)
@@ -686,13 +735,13 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
             LaneList ll;
             ll.items.p = c->d_rerun_items.p; ll.items.cap = c->d_rerun_items.cap;
             ll.n = (uint32_t)items.size(); ll.cols = cols; ll.cell_cols = cols;
-            const int rc = run_lane_passes(c, mode, qps[q], c->qm[q], ll, c->d_scores.p + (size_t)q * S, c->stream3, c->rerun_scratch);
+            const int rc = run_lane_passes(c, mode, qps[q], qm[q], ll, c->d_scores.p + (size_t)q * S, c->stream3, c->rerun_scratch);
             ll.items.p = nullptr; ll.items.cap = 0;           // borrowed
             return rc;
         };
         for (uint32_t k = 0; k < qn; ++k) {
             const uint32_t q = qn - 1 - k;
-            const long bound = (long)c->qm[q] * c->max_pos;     // no alignment of this query can score more
+            const long bound = (long)qm[q] * c->max_pos;     // no alignment of this query can score more
             if (!((main_mode == Mode::F16 && bound >= 2048) || bound >= 32767)) continue;
             HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_query[2 * q], 0));
             HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_query[2 * q + 1], 0));
@@ -741,7 +790,7 @@ int search_device(swimm_hip_ctx *c, uint64_t *slots_out)
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->kernel_ms = ms;
+    c->kernel_ms += ms;
     uint32_t werr = 0;
     HIP_TRY(hipMemcpy(&werr, c->d_err.p, sizeof werr, hipMemcpyDeviceToHost));
     if (werr) return fail("pipeline watchdog expired (code %u): results discarded", werr);
@@ -921,23 +970,39 @@ int swimm_hip_clear_db(swimm_hip_ctx *c)
     return 0;
 }
 
+// queries per batch: the score rows of a batch (4 B per query and database slot) stay within the budget
+static uint32_t query_batch(const swimm_hip_ctx *c)
+{
+    const uint64_t S = (uint64_t)c->groups.size() * kGroupSeqs;
+    const uint64_t budget = (uint64_t)c->opt_score_mib << 20;
+    const uint64_t per_query = std::max<uint64_t>(1, S * sizeof(int32_t));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->qm.size(), budget / per_query));
+}
+
+static void reset_stats(swimm_hip_ctx *c) { c->kernel_ms = 0; c->cells = 0; c->promoted = 0; c->promoted16 = 0; c->launches = 0; }
+
 int swimm_hip_search(swimm_hip_ctx *c, int32_t *scores, uint64_t score_stride, double *work_time)
 {
     if (!c || !scores) return fail("swimm_hip_search: NULL argument");
     const double t0 = now_s();
-    uint64_t S = 0;
-    if (search_device(c, &S)) return 1;
-    // score scatter (X3, MICsearch.c:333-334): each chunk's slice goes to its global offset
-    const uint32_t qn = (uint32_t)c->qm.size();
-    for (const ChunkRec &ch : c->chunks) {
-        if (ch.first_seq + ch.n_seq > score_stride)
-            return fail("swimm_hip_search: chunk at %llu+%llu exceeds score_stride %llu", (unsigned long long)ch.first_seq,
-                        (unsigned long long)ch.n_seq, (unsigned long long)score_stride);
-        HIP_TRY(hipMemcpy2DAsync(scores + ch.first_seq, score_stride * sizeof(int32_t),
-                                 c->d_scores.p + (size_t)ch.group0 * kGroupSeqs, S * sizeof(int32_t),
-                                 ch.n_seq * sizeof(int32_t), qn, hipMemcpyDeviceToHost, c->stream));
+    reset_stats(c);
+    const uint32_t qtotal = (uint32_t)c->qm.size(), B = query_batch(c);
+    if (qtotal == 0) return fail("swimm_hip_search: no queries set");
+    for (uint32_t qb = 0; qb < qtotal; qb += B) {
+        const uint32_t qe = std::min(qtotal, qb + B), qn = qe - qb;
+        uint64_t S = 0;
+        if (search_device(c, qb, qe, &S)) return 1;
+        // score scatter (X3, MICsearch.c:333-334): each chunk's slice goes to its global offset
+        for (const ChunkRec &ch : c->chunks) {
+            if (ch.first_seq + ch.n_seq > score_stride)
+                return fail("swimm_hip_search: chunk at %llu+%llu exceeds score_stride %llu", (unsigned long long)ch.first_seq,
+                            (unsigned long long)ch.n_seq, (unsigned long long)score_stride);
+            HIP_TRY(hipMemcpy2DAsync(scores + (size_t)qb * score_stride + ch.first_seq, score_stride * sizeof(int32_t),
+                                     c->d_scores.p + (size_t)ch.group0 * kGroupSeqs, S * sizeof(int32_t),
+                                     ch.n_seq * sizeof(int32_t), qn, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
     if (work_time) *work_time = now_s() - t0;
     return 0;
 }
@@ -948,68 +1013,74 @@ int swimm_hip_search_topr(swimm_hip_ctx *c, uint32_t r, uint64_t n_valid, int32_
     if (!c || !top_scores || !top_index) return fail("swimm_hip_search_topr: NULL argument");
     if (r == 0) return fail("swimm_hip_search_topr: r must be > 0");
     const double t0 = now_s();
-    uint64_t S = 0;
-    if (search_device(c, &S)) return 1;
-    const uint32_t qn = (uint32_t)c->qm.size();
+    reset_stats(c);
+    const uint32_t qtotal = (uint32_t)c->qm.size(), B = query_batch(c);
+    if (qtotal == 0) return fail("swimm_hip_search_topr: no queries set");
     typedef std::pair<int32_t, int64_t> Hit;   // larger pair first == score desc, then larger index first (utils.c:12,52)
-    if (r <= 64) {
-        // device path: per-block top-64 candidate keys, final selection over n_blocks*64 keys on the host
-        std::vector<int64_t> gbase(c->groups.size());
-        std::vector<uint32_t> gvalid(c->groups.size());
-        for (const ChunkRec &ch : c->chunks)
-            for (uint32_t i = 0; i < ch.n_groups; ++i) {
-                const uint64_t first = ch.first_seq + (uint64_t)i * kGroupSeqs;
-                uint64_t cnt = (uint64_t)i * kGroupSeqs < ch.n_seq ? std::min<uint64_t>(kGroupSeqs, ch.n_seq - (uint64_t)i * kGroupSeqs) : 0;
-                if (first >= n_valid) cnt = 0; else cnt = std::min<uint64_t>(cnt, n_valid - first);
-                gbase[ch.group0 + i] = (int64_t)first;
-                gvalid[ch.group0 + i] = (uint32_t)cnt;
+    for (uint32_t qb = 0; qb < qtotal; qb += B) {
+        const uint32_t qe = std::min(qtotal, qb + B), qn = qe - qb;
+        uint64_t S = 0;
+        if (search_device(c, qb, qe, &S)) return 1;
+        int32_t *out_s = top_scores + (size_t)qb * r;
+        int64_t *out_i = top_index + (size_t)qb * r;
+        if (r <= 64) {
+            // device path: per-block top-64 candidate keys, final selection over n_blocks*64 keys on the host
+            std::vector<int64_t> gbase(c->groups.size());
+            std::vector<uint32_t> gvalid(c->groups.size());
+            for (const ChunkRec &ch : c->chunks)
+                for (uint32_t i = 0; i < ch.n_groups; ++i) {
+                    const uint64_t first = ch.first_seq + (uint64_t)i * kGroupSeqs;
+                    uint64_t cnt = (uint64_t)i * kGroupSeqs < ch.n_seq ? std::min<uint64_t>(kGroupSeqs, ch.n_seq - (uint64_t)i * kGroupSeqs) : 0;
+                    if (first >= n_valid) cnt = 0; else cnt = std::min<uint64_t>(cnt, n_valid - first);
+                    gbase[ch.group0 + i] = (int64_t)first;
+                    gvalid[ch.group0 + i] = (uint32_t)cnt;
+                }
+            const int n_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(256, S / 1024));
+            HIP_TRY(c->d_gbase.reserve(gbase.size()));
+            HIP_TRY(c->d_gvalid.reserve(gvalid.size()));
+            HIP_TRY(c->d_keys.reserve((size_t)qn * n_blocks * 64));
+            HIP_TRY(hipMemcpyAsync(c->d_gbase.p, gbase.data(), gbase.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_gvalid.p, gvalid.data(), gvalid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            for (uint32_t q = 0; q < qn; ++q)
+                HIP_TRY(launch_topk64(c->d_scores.p + (size_t)q * S, S, c->d_gbase.p, c->d_gvalid.p,
+                                      c->d_keys.p + (size_t)q * n_blocks * 64, n_blocks, c->stream));
+            std::vector<unsigned long long> keys((size_t)qn * n_blocks * 64);
+            HIP_TRY(hipMemcpyAsync(keys.data(), c->d_keys.p, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (uint32_t q = 0; q < qn; ++q) {
+                unsigned long long *kq = keys.data() + (size_t)q * n_blocks * 64;
+                const size_t nk = (size_t)n_blocks * 64;
+                const size_t k = std::min<size_t>(r, nk);
+                std::partial_sort(kq, kq + k, kq + nk, std::greater<unsigned long long>());
+                for (uint32_t i = 0; i < r; ++i) {
+                    const bool have = i < k && kq[i] != 0;
+                    const unsigned long long key = have ? kq[i] - 1 : 0;
+                    out_s[(size_t)q * r + i] = have ? (int32_t)(key >> 32) : -1;
+                    out_i[(size_t)q * r + i] = have ? (int64_t)(key & 0xFFFFFFFFull) : -1;
+                }
             }
-        const int n_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(256, S / 1024));
-        HIP_TRY(c->d_gbase.reserve(gbase.size()));
-        HIP_TRY(c->d_gvalid.reserve(gvalid.size()));
-        HIP_TRY(c->d_keys.reserve((size_t)qn * n_blocks * 64));
-        HIP_TRY(hipMemcpyAsync(c->d_gbase.p, gbase.data(), gbase.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_gvalid.p, gvalid.data(), gvalid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        for (uint32_t q = 0; q < qn; ++q)
-            HIP_TRY(launch_topk64(c->d_scores.p + (size_t)q * S, S, c->d_gbase.p, c->d_gvalid.p,
-                                  c->d_keys.p + (size_t)q * n_blocks * 64, n_blocks, c->stream));
-        std::vector<unsigned long long> keys((size_t)qn * n_blocks * 64);
-        HIP_TRY(hipMemcpyAsync(keys.data(), c->d_keys.p, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            continue;
+        }
+        // r > 64: whole score rows come back and the host selects (O(N log r))
+        std::vector<int32_t> host((size_t)qn * S);
+        HIP_TRY(hipMemcpyAsync(host.data(), c->d_scores.p, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<Hit> hits;
         for (uint32_t q = 0; q < qn; ++q) {
-            unsigned long long *kq = keys.data() + (size_t)q * n_blocks * 64;
-            const size_t nk = (size_t)n_blocks * 64;
-            const size_t k = std::min<size_t>(r, nk);
-            std::partial_sort(kq, kq + k, kq + nk, std::greater<unsigned long long>());
+            hits.clear();
+            for (const ChunkRec &ch : c->chunks) {
+                const int32_t *row = host.data() + (size_t)q * S + (size_t)ch.group0 * kGroupSeqs;
+                for (uint64_t i = 0; i < ch.n_seq; ++i) {
+                    const uint64_t gi = ch.first_seq + i;
+                    if (gi < n_valid) hits.push_back(Hit(row[i], (int64_t)gi));
+                }
+            }
+            const size_t k = std::min<size_t>(r, hits.size());
+            std::partial_sort(hits.begin(), hits.begin() + k, hits.end(), std::greater<Hit>());
             for (uint32_t i = 0; i < r; ++i) {
-                const bool have = i < k && kq[i] != 0;
-                const unsigned long long key = have ? kq[i] - 1 : 0;
-                top_scores[(size_t)q * r + i] = have ? (int32_t)(key >> 32) : -1;
-                top_index[(size_t)q * r + i] = have ? (int64_t)(key & 0xFFFFFFFFull) : -1;
+                out_s[(size_t)q * r + i] = i < k ? hits[i].first : -1;
+                out_i[(size_t)q * r + i] = i < k ? hits[i].second : -1;
             }
-        }
-        if (work_time) *work_time = now_s() - t0;
-        return 0;
-    }
-    // r > 64: whole score rows come back and the host selects (heap, O(N log r))
-    std::vector<int32_t> host((size_t)qn * S);
-    HIP_TRY(hipMemcpyAsync(host.data(), c->d_scores.p, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<Hit> hits;
-    for (uint32_t q = 0; q < qn; ++q) {
-        hits.clear();
-        for (const ChunkRec &ch : c->chunks) {
-            const int32_t *row = host.data() + (size_t)q * S + (size_t)ch.group0 * kGroupSeqs;
-            for (uint64_t i = 0; i < ch.n_seq; ++i) {
-                const uint64_t gi = ch.first_seq + i;
-                if (gi < n_valid) hits.push_back(Hit(row[i], (int64_t)gi));
-            }
-        }
-        const size_t k = std::min<size_t>(r, hits.size());
-        std::partial_sort(hits.begin(), hits.begin() + k, hits.end(), std::greater<Hit>());
-        for (uint32_t i = 0; i < r; ++i) {
-            top_scores[(size_t)q * r + i] = i < k ? hits[i].first : -1;
-            top_index[(size_t)q * r + i] = i < k ? hits[i].second : -1;
         }
     }
     if (work_time) *work_time = now_s() - t0;
@@ -1050,6 +1121,12 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         c->opt_maxW = value;
     } else if (!strcmp(key, "force_i32")) {
         c->opt_force_i32 = value != 0;
+    } else if (!strcmp(key, "bnd_mib")) {
+        if (value < 1) return fail("bnd_mib must be >= 1");
+        c->opt_bnd_mib = value;
+    } else if (!strcmp(key, "score_mib")) {
+        if (value < 0) return fail("score_mib must be >= 0 (0 = one query per batch)");
+        c->opt_score_mib = value;
     } else if (!strcmp(key, "tail_frac")) {
         if (value < 1 || value > 1000) return fail("tail_frac must be 1..1000 (percent of a CU's mean load)");
         c->opt_tail_frac = value;

@@ -48,7 +48,9 @@ def test_golden_all_cases(searcher, gin, golden):
                                   {"f16": 0}, {"f16": 0, "tail_mode": 2}, {"f16": 1, "rows_per_wave": 24, "tail_mode": 2},
                                   {"dynamic": 0}, {"dynamic": 0, "tail_mode": 2, "f16": 0}, {"dynamic": 0, "tail_mode": 2, "max_waves": 3},
                                   {"rows_per_wave": 8}, {"rows_per_wave": 12, "tail_mode": 2}, {"rows_per_wave": 20}, {"rows_per_wave": 28, "waves": 4},
-                                  {"rows_per_wave": 36}, {"rows_per_wave": 36, "waves": 3, "tail_mode": 2}, {"rows_per_wave": 20, "waves": 7}])
+                                  {"rows_per_wave": 36}, {"rows_per_wave": 36, "waves": 3, "tail_mode": 2}, {"rows_per_wave": 20, "waves": 7},
+                                  {"score_mib": 0}, {"score_mib": 0, "tail_mode": 2}, {"bnd_mib": 1, "tail_mode": 2},
+                                  {"bnd_mib": 1, "tail_mode": 2, "rows_per_wave": 16, "waves": 4}, {"bnd_mib": 1, "tail_mode": 2, "force_i32": 1}])
 def test_golden_kernel_variants(gin, golden, opts):
     q, pp, chunked = gin
     N = golden["search"]["n_sequences"]
@@ -96,6 +98,19 @@ def test_seeded_db_vs_oracle(searcher):
         for qi in range(3):
             s, i = port.topr(want[qi, :n], r)
             assert np.array_equal(ts[qi], s) and np.array_equal(ti[qi], i), (r, qi)
+    # one query per batch (score-row budget) and a boundary buffer cut into runs: same answers
+    searcher.set_option("score_mib", 0)
+    searcher.set_option("bnd_mib", 1)
+    got2, _ = searcher.search(vc * 128)
+    assert np.array_equal(got2, want)
+    for r in (7, 80):
+        ts, ti, _ = searcher.search_topr(r, n)
+        for qi in range(3):
+            s, i = port.topr(want[qi, :n], r)
+            assert np.array_equal(ts[qi], s) and np.array_equal(ti[qi], i), (r, qi)
+    assert searcher.last_plan(2)["rows_per_wave"] > 0
+    searcher.set_option("score_mib", 32768)
+    searcher.set_option("bnd_mib", 16384)
     # n_valid below the resident count: padding / excluded lanes never show up
     ts, ti, _ = searcher.search_topr(10, n - 77)
     for qi in range(3):

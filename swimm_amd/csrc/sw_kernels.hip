@@ -220,9 +220,12 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
         }
     }
     uint32_t it, it_end = 0;      // current item id; static mode: end of this workgroup's range
-    // dynamic mode, wave 0: pulls from the global cursor run two items ahead of the item being aligned.  The atomic
-    // is issued at the end of the step that starts an item and its result is published to seq[] at the top of the
-    // next step, so the returned value is only live across the barrier, not across the column loop.
+    // dynamic mode, wave 0: every workgroup knows its next item while it aligns the current one (the first two are
+    // dealt below).  When it finishes an item it pulls the one after the next from the global cursor: the atomic is
+    // issued at the end of that step and its result is published to seq[] at the top of the next step, so the
+    // returned value is only live across the barrier, not across the column loop.  (Pulling at the START of an item
+    // dealt a third round at time 0, in the wrong order: the workgroup with the longest first group got the longest
+    // third one -- 35 % on a 1e8-residue database.)
     uint32_t pending = 0, pub = 2;
     bool pending_valid = false;
     if (DYN) {
@@ -263,6 +266,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 
 #ifdef SWIMM_STAMPS
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, sumA = 0, sumB = 0, sumC = 0, sumD = 0, nact = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int s = 0;; ++s) {
         if (DYN) total = __builtin_amdgcn_readfirstlane(*(volatile int *)total_lds);   // same value in every wave: written before the last barrier
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             ++pub;
             pending_valid = false;
         }
-        bool started = false;
+        bool pull = false;
         const int c = s - k;                      // chunk index of this wave in the workgroup's sequence
         STAMP(tA);
         if (c >= 0 && it != kNoItem) {            // wave-uniform
@@ -291,7 +295,6 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 best = Ops::zero(); diag_top = Ops::zero();
 #pragma unroll
                 for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
-                started = true;
             }
             // database residues of this chunk: 4 columns of the lane's sequence(s).  They were requested one
             // step ago (below): right after the barrier every wave would otherwise stall on this global load
@@ -438,13 +441,14 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 cc = 0;
                 ++n;
                 it = next_it;
+                pull = true;
             }
 #ifdef SWIMM_STAMPS
             STAMP(tD);
             sumA += tB - tA; sumB += tC - tB; sumC += tD - tC; nact++;
 #endif
         }
-        if (DYN && k == 0 && started) {          // one pull per item started keeps the look-ahead at two items
+        if (DYN && k == 0 && pull) {             // one pull per item finished: the workgroup that finishes first gets the longest group left
             if (lane == 0) pending = atomicAdd(p.queue, 1u);
             pending_valid = true;
         }
@@ -458,6 +462,13 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     if (p.stamps && lane == 0) {
         atomicAdd(p.stamps + k * 8 + 0, sumA); atomicAdd(p.stamps + k * 8 + 1, sumB); atomicAdd(p.stamps + k * 8 + 2, sumC);
         atomicAdd(p.stamps + k * 8 + 3, sumD); atomicAdd(p.stamps + k * 8 + 4, nact); atomicAdd(p.stamps + k * 8 + 5, (unsigned long long)(total + W - 1));
+        atomicMax(p.stamps + k * 8 + 6, (unsigned long long)(total + W - 1)); atomicMax(p.stamps + k * 8 + 7, sumA + sumB + sumC + sumD);
+        if (k == 0) {   // when do workgroups end?  (100 MHz wall clock, same on every CU)
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            atomicAdd(p.stamps + 15 * 8 + 0, t - t_begin); atomicMax(p.stamps + 15 * 8 + 1, t - t_begin);
+            atomicMin(p.stamps + 15 * 8 + 2, t_begin); atomicMax(p.stamps + 15 * 8 + 3, t); atomicAdd(p.stamps + 15 * 8 + 4, 1ull);
+            if (blockIdx.x < 1024) { p.stamps[128 + blockIdx.x] = t; p.stamps[128 + 1024 + blockIdx.x] = (unsigned long long)total; p.stamps[128 + 2048 + blockIdx.x] = t_begin; }
+        }
     }
 #endif
 }

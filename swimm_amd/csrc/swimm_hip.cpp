@@ -487,8 +487,9 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
             p.last_pass = pass == qp.passes - 1;
             p.out = out_row;
 #ifdef SWIMM_STAMPS
-            HIP_TRY(c->d_stamps.reserve(16 * 8));
+            HIP_TRY(c->d_stamps.reserve(16 * 8 + 3072));
             HIP_TRY(hipMemsetAsync(c->d_stamps.p, 0, 16 * 8 * sizeof(unsigned long long), c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_stamps.p + 15 * 8 + 2, 0xff, sizeof(unsigned long long), c->stream));   // min slot
             p.stamps = c->d_stamps.p;
 #endif
             p.err = c->d_err.p;
@@ -502,6 +503,16 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
                     fprintf(stderr, "stamps wave %2d: load/wait %8.0f  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active of %llu steps per wg)\n",
                             w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4],
                             (double)h[w * 8 + 3] / h[w * 8 + 4], h[w * 8 + 4] / pl.n_wg, h[w * 8 + 5] / pl.n_wg);
+                fprintf(stderr, "stamps: most steps of any workgroup %llu, longest workgroup %.0f cycles\n", h[6], (double)h[7]);
+                if (getenv("SWIMM_STAMPS_DUMP")) {
+                    std::vector<unsigned long long> pw(3072);
+                    HIP_TRY(hipMemcpy(pw.data(), c->d_stamps.p + 128, pw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                    const unsigned long long t0 = h[15 * 8 + 2];
+                    for (int b = 0; b < std::min(pl.n_wg, 1024); b += (b < 16 ? 1 : 37))
+                        fprintf(stderr, "  wg %4d: start %7.1f us end %7.1f us chunks %llu\n", b, (double)(pw[2048 + b] - t0) / 100.0, (double)(pw[b] - t0) / 100.0, pw[1024 + b]);
+                }
+                fprintf(stderr, "stamps: workgroup run time mean %.1f us, longest %.1f us; first start to last end %.1f us (%llu workgroups)\n",
+                        (double)h[15 * 8 + 0] / h[15 * 8 + 4] / 100.0, (double)h[15 * 8 + 1] / 100.0, (double)(h[15 * 8 + 3] - h[15 * 8 + 2]) / 100.0, h[15 * 8 + 4]);
             }
 #endif
             c->launches++;

@@ -78,7 +78,6 @@ struct LaneParams {
     int32_t *out;
     int goe, ge;
     uint32_t *err;              // watchdog word
-    int high_prio;              // 1: waves run at s_setprio 3 (re-runs a query is waiting for); 0: beside the bulk at priority 0
 };
 size_t lane_lds_bytes();
 hipError_t launch_lane(Mode mode, int n_wg, const LaneParams &p, hipStream_t s);

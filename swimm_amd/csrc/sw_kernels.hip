@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // these waves carry the critical path (the longest alignments, or the re-runs a query is waiting for) and share
     // the SIMDs with bulk waves that run at priorities 3..0: keep them at the top
-    if (p.high_prio) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int PS = prof_row_bytes(RP);
     const uint32_t pass = blockIdx.x / p.wg_per_pass;

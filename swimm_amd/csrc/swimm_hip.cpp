@@ -112,9 +112,8 @@ struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; };
 struct swimm_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    static constexpr int kTailStreams = 1;
-    hipStream_t tail_stream[kTailStreams] = {};   // lane-systolic tails run beside the bulk kernels, several queries' at once
-    hipEvent_t ev_tails[kTailStreams] = {};
+    hipStream_t stream2 = nullptr;      // lane-systolic tail runs beside the bulk kernel
+    hipEvent_t ev_tail = nullptr;
     hipStream_t stream3 = nullptr;      // promotion re-runs
     hipEvent_t ev_ready = nullptr, ev_tail3 = nullptr;
     std::vector<hipEvent_t> ev_query;   // [2q] bulk done, [2q+1] tail done
@@ -157,7 +156,7 @@ struct swimm_hip_ctx {
     DevBuf<unsigned long long> d_keys;
     DevBuf<uint32_t> d_err;             // pipeline watchdog word
     DevBuf<unsigned long long> d_stamps;   // diagnostic build only
-    LaneScratch tail_scratch[kTailStreams];   // one per tail stream (long-sequence tail)
+    LaneScratch tail_scratch;           // lane kernel on stream 2 (long-sequence tail)
     LaneScratch rerun_scratch;          // lane kernel on stream 3 (promotion re-runs)
     DevBuf<LaneItem> d_rerun_items;
     DevBuf<uint32_t> d_satlist;
@@ -553,7 +552,6 @@ int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, con
     p.goe = c->open_gap + c->extend_gap;
     p.ge = c->extend_gap;
     p.err = c->d_err.p;
-    p.high_prio = getenv("SWIMM_HIP_TAIL_PRIO") ? atoi(getenv("SWIMM_HIP_TAIL_PRIO")) : (&sc == &c->rerun_scratch ? 1 : 1);
     HIP_TRY(hipMemsetAsync(sc.queue.p, 0, passes * sizeof(uint32_t), st));
     if (passes > 1) HIP_TRY(hipMemsetAsync(sc.prog.p, 0, need_prog * sizeof(uint32_t), st));
     HIP_TRY(launch_lane(mode, passes * per_pass, p, st));
@@ -609,7 +607,6 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         uint32_t longest = 0;
         for (const GroupDesc &g : c->groups) longest = std::max(longest, g.ncols);
         lane_room = c->opt_tail_mode == 1 || (double)longest > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
-        if (getenv("SWIMM_HIP_NO_LANE_ROOM")) lane_room = false;   // tuning experiment
     }
     std::vector<QueryPlan> qps(qn);
     size_t prof_elems = 0;
@@ -667,8 +664,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
-        for (LaneScratch &ts : c->tail_scratch)
-            if (reserve_lane_scratch(ts, tail_cols, tail_items, max_passes)) return 1;
+        if (reserve_lane_scratch(c->tail_scratch, tail_cols, tail_items, max_passes)) return 1;
         if (reserve_lane_scratch(c->rerun_scratch, (size_t)1 << 22, 4096, max_passes)) return 1;
         HIP_TRY(c->d_satlist.reserve((size_t)(1u << 16) + 1));
         HIP_TRY(c->d_rerun_items.reserve(4096));
@@ -677,7 +673,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     HIP_TRY(hipMemsetAsync(c->d_err.p, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
-    for (hipStream_t ts : c->tail_stream) HIP_TRY(hipStreamWaitEvent(ts, c->ev_ready, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
     HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
     while (c->ev_query.size() < 2 * (size_t)qn) {
         hipEvent_t e;
@@ -699,11 +695,10 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         // bulk kernel: 3 bulk waves (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly
         // (one tail launch at a time: several at once were measured 5 % slower on c3, and the chained passes of
         // concurrent launches could wait for each other's workgroups)
-        const int tsi = (int)(k % swimm_hip_ctx::kTailStreams);
-        if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, c->tail_stream[tsi], c->tail_scratch[tsi])) return 1;
+        if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, c->stream2, c->tail_scratch)) return 1;
         if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row)) return 1;
         HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
-        HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->tail_stream[tsi]));
+        HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->stream2));
     }
     // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
     // f16 results >= 2048 are re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; each
@@ -791,10 +786,8 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             if (rerun(q, Mode::I32, items)) return 1;
         }
     }
-    for (int i = 0; i < swimm_hip_ctx::kTailStreams; ++i) {
-        HIP_TRY(hipEventRecord(c->ev_tails[i], c->tail_stream[i]));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tails[i], 0));
-    }
+    HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
     HIP_TRY(hipEventRecord(c->ev_tail3, c->stream3));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail3, 0));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -840,10 +833,8 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     swimm_hip_ctx *c = new swimm_hip_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
-    bool tails_ok = true;
-    for (int i = 0; i < swimm_hip_ctx::kTailStreams; ++i)
-        tails_ok = tails_ok && hipStreamCreate(&c->tail_stream[i]) == hipSuccess && hipEventCreateWithFlags(&c->ev_tails[i], hipEventDisableTiming) == hipSuccess;
-    if (!tails_ok || hipStreamCreate(&c->stream) != hipSuccess ||
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess) {
@@ -860,14 +851,14 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
     c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
-    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); for (LaneScratch &ts : c->tail_scratch) ts.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
+    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    for (hipEvent_t e : c->ev_tails) if (e) (void)hipEventDestroy(e);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     if (c->ev_tail3) (void)hipEventDestroy(c->ev_tail3);
     for (hipEvent_t e : c->ev_query) (void)hipEventDestroy(e);
-    for (hipStream_t ts : c->tail_stream) if (ts) (void)hipStreamDestroy(ts);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

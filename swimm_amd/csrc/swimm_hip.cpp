@@ -1,8 +1,9 @@
 // swimm_hip.cpp -- C-ABI shim of libswimm_hip.so (see include/swimm_hip.h).
 //
-// Host-side orchestration of the gfx950 kernels in sw_kernels.hip: device-resident database,
-// per-query launch plan (rows per wave T, waves per workgroup W, passes), static LPT partition
-// of the device groups over persistent workgroups, int16 -> int32 promotion, score scatter.
+// Host-side orchestration of the gfx950 kernels in sw_kernels.hip: device-resident database, per-query
+// launch plan (rows per wave T, waves per workgroup W, passes) from a measured rate table, longest-first work
+// lists for the persistent workgroups (dynamic queue, static partition as an option), the long-sequence tail
+// on a second stream, the binary16 -> int16 -> int32 promotion ladder on a third, top-r and score scatter.
 // Structural template: mic_search_knc_ap_multiple_chunks (MICsearch.c:4-354) -- X1 = set_queries,
 // X2-in = add_chunk (kept resident), compute = search, X3 = scatter into the caller's scores.
 #include "../../include/swimm_hip.h"
@@ -119,18 +120,20 @@ struct swimm_hip_ctx {
     std::vector<hipEvent_t> ev_query;   // [2q] bulk done, [2q+1] tail done
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cu = 0;
-    // options
-    int opt_T = 0, opt_maxW = 0, opt_W = 0, opt_force_i32 = 0, opt_wgs_per_cu = 0;   // 0 = chosen per query
-    std::map<int, double> imbalance_cache;   // n_wg -> LPT makespan / mean load of the resident database (bulk groups)
-    int regs_cache[3][40] = {};            // VGPRs of sw_pipe_kernel<T, tier>, looked up once
+    // options (swimm_hip_set_option)
+    int opt_T = 0, opt_maxW = 0, opt_W = 0, opt_wgs_per_cu = 0;   // launch shape: 0 = chosen per query
+    int opt_force_i32 = 0;              // 1: everything in int32
+    int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
-    int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
-    int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
     int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
     int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
+    int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
+    int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
+    // caches that depend on the resident database / the code objects
+    std::map<int, double> imbalance_cache;   // n_wg -> LPT makespan / mean load of the resident database (bulk groups)
+    int regs_cache[3][40] = {};         // VGPRs of sw_pipe_kernel<T, tier>, looked up once
     DevBuf<uint32_t> d_queue;           // one cursor per pipeline launch of a search
     uint32_t queue_next = 0;
-    int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
     // queries (host copies; profiles are built per search because T/W may change)
     std::vector<int8_t> qcodes;
     std::vector<uint16_t> qm;

@@ -233,14 +233,14 @@ double plan_imbalance(swimm_hip_ctx *c, int n_wg)
 // (tools/plan_sweep.py on one MI355X, profiles/r01_plan_sweep.txt).  W = 4, 8, 12, 16 put the same number of waves
 // on each of the CU's 4 SIMDs; any other W runs like the next multiple of 4 (2 x 6 waves behave like 4+4+2+2).
 static const float kShapeGcups[8][16] = {
-    {2142, 3826, 4468, 5585, 5950, 6378, 6876, 7489, 6962, 5951, 6690, 7265, 6738, 6696, 5827, 7542},     // T=8
-    {2719, 4343, 5328, 6655, 6497, 6901, 7216, 8026, 7331, 6558, 7291, 7857, 7241, 7140, 7606, 8042},     // T=12
-    {3158, 4664, 5951, 7588, 6471, 5452, 7046, 8023, 5258, 5864, 6434, 6983, 6010, 6475, 6929, 7379},     // T=16
-    {3390, 4995, 6347, 7702, 5490, 5553, 7165, 8126, 5502, 6106, 6696, 7307, 6106, 6716, 7184, 7654},     // T=20
-    {3640, 5220, 6748, 7980, 5506, 6260, 7252, 8122, 5633, 6283, 6904, 7526, 6337, 6889, 7359, 7846},     // T=24
-    {3832, 5521, 6751, 8074, 6148, 6257, 7257, 8253, 5799, 6429, 7072, 7704, 6514, 7018, 7507, 8002},     // T=28
-    {3627, 5778, 6902, 8352, 4583, 5476, 6365, 7267, 5889, 6527, 7168, 7812, 0, 0, 0, 0},                 // T=32
-    {3809, 5958, 6024, 8419, 4664, 5594, 6460, 7449, 5960, 6630, 7030, 7934, 0, 0, 0, 0},                 // T=36
+    {2266, 3928, 4832, 6058, 5717, 6894, 7079, 7660, 7008, 5520, 6739, 7313, 6811, 6748, 5836, 7562},     // T=8
+    {2809, 4488, 5797, 7254, 6593, 7065, 7299, 8107, 7423, 6014, 7321, 7880, 7264, 7154, 7618, 8065},     // T=12
+    {3222, 5019, 6511, 7937, 5774, 5152, 7068, 8043, 5267, 5854, 6438, 6983, 6022, 6494, 6932, 7386},     // T=16
+    {3404, 5399, 6923, 8094, 4988, 5536, 7173, 8149, 5500, 6097, 6699, 7307, 6114, 6728, 7189, 7666},     // T=20
+    {3718, 5836, 7306, 8342, 5485, 6312, 7257, 8171, 5661, 6295, 6900, 7530, 6338, 6886, 7357, 7858},     // T=24
+    {3798, 5878, 7162, 8368, 6168, 6278, 7274, 8263, 5791, 6432, 7064, 7698, 6514, 7005, 7500, 8004},     // T=28
+    {3788, 6116, 6238, 8438, 4572, 5507, 6388, 7272, 5864, 6525, 7183, 7806, 0, 0, 0, 0},                 // T=32
+    {3929, 6424, 5650, 8514, 4674, 5601, 6434, 7430, 5960, 6630, 7001, 7931, 0, 0, 0, 0},                 // T=36
 };
 
 // Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the shape with the lowest

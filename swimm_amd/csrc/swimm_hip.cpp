@@ -244,10 +244,10 @@ static const float kShapeGcups[8][16] = {
 };
 
 // Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the shape with the lowest
-// predicted time per database column, passes x (T x W padded rows) / measured rate of that shape.  With more than
-// one pass the strip boundaries go through HBM and the first wave waits for its loads: not measurable for W >= 8
-// (every query of 464 ... 5478 rows on a c5-shaped shard runs at 0.97 of its shape's rate, like the one-pass
-// ones), 17 % for the 4-wave shapes.
+// predicted time, passes x (padded cells of a pass / measured rate of that shape x makespan factor + launch cost).
+// With more than one pass the strip boundaries go through HBM and the first wave waits for its loads: not
+// measurable for W >= 8 (every query of 464 ... 5478 rows on a c5-shaped shard runs at 0.97 of its shape's rate,
+// like the one-pass ones), 17 % for the 4-wave shapes.
 // `room_for_lane_waves`: the database has a long-sequence tail that the lane kernel aligns on a second stream
 // while this kernel runs; only shapes that leave the 80 VGPRs per SIMD lane a lane-systolic wave needs are
 // admitted (e.g. 3 waves x 144, 4 x 104).
@@ -270,8 +270,12 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, Qu
                 const int alloc = (c->regs_cache[(int)mode][T] + 7) / 8 * 8;
                 if (alloc * ((per_cu * W + 3) / 4) > 512 - 80) continue;
             }
-            const double cost = (double)passes * T * W / kShapeGcups[ti][W - 1] * (passes > 1 ? (W >= 8 ? 1.005 : 1.17) : 1.0)
-                                * plan_imbalance(c, c->num_cu * per_cu);
+            // seconds: every pass aligns T x W rows against the whole resident database at the shape's rate, and costs
+            // a launch (pipeline fill and drain, staging, the last workgroups running alone: ~0.15 ms, which is what
+            // makes fewer, taller passes the better plan on a database of 1e8 residues)
+            const double pass_s = (double)c->total_cols * kGroupSeqs * T * W / ((double)kShapeGcups[ti][W - 1] * 1e9)
+                                  * (passes > 1 && W < 8 ? 1.17 : 1.0) * plan_imbalance(c, c->num_cu * per_cu);
+            const double cost = passes * (pass_s + 150e-6);
             if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
                 best_cost = cost;
                 out->T = T; out->W = W; out->passes = passes; out->mpad = (uint32_t)(passes * W * T);

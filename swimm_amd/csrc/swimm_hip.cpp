@@ -816,13 +816,23 @@ int swimm_hip_abi_version(void) { return SWIMM_HIP_ABI_VERSION; }
 
 const char *swimm_hip_last_error(void) { return g_err.c_str(); }
 
+// Test hook: SWIMM_HIP_VIRTUAL_GPUS=N presents N devices on a box with fewer; virtual device d runs on physical
+// device d % real count.  Lets the multi-GPU host logic (sharding, one thread per device, merging) be exercised on
+// the one-GPU test box; results are identical by construction, timing is meaningless.
+static int virtual_gpus(int real)
+{
+    const char *v = getenv("SWIMM_HIP_VIRTUAL_GPUS");
+    const int n = v ? atoi(v) : 0;
+    return real > 0 && n > real ? n : real;
+}
+
 int swimm_hip_device_count(void)
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { fail("hipGetDeviceCount: %s", hipGetErrorString(e)); return 0; }
     if (n == 0) fail("no HIP device visible");
-    return n;
+    return virtual_gpus(n);
 }
 
 int swimm_hip_create(int device, swimm_hip_ctx **out)
@@ -831,7 +841,8 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     *out = nullptr;
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return fail("swimm_hip_create: device %d not in [0,%d)", device, n);
+    if (device < 0 || device >= virtual_gpus(n)) return fail("swimm_hip_create: device %d not in [0,%d)", device, virtual_gpus(n));
+    device %= std::max(n, 1);
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));

@@ -136,3 +136,18 @@ def test_search_mode2_hybrid_listing(dbprefix, golden, host_share):
     check_listing(p.stdout, golden, dbprefix, "blosum62_g10_e2", 413)
     assert "Execution mode:\t\t\tConcurrent host CPU and MI355X (4 CPU threads and 1 GPUs)\n" in p.stdout
     assert f"Host CPU share:\t\t\t{host_share} sequences" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_search_over_several_devices(dbprefix, golden, mode):
+    """-x 3 on the one-GPU box through the virtual-device hook: chunks dealt to three contexts, lists merged"""
+    q = os.path.join(GOLDEN, golden["query_fasta"])
+    env = dict(os.environ, SWIMM_HIP_VIRTUAL_GPUS="3", SWIMM_HYBRID_CPU_SEQUENCES="128")
+    p = subprocess.run([SWIMM, "-S", "search", "-q", q, "-d", dbprefix, "-m", mode, "-x", "3", "-k", "12000", "-r", "413", "-c", "4"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    check_listing(p.stdout, golden, dbprefix, "blosum62_g10_e2", 413)
+    assert "(3 GPUs)" in p.stdout or "and 3 GPUs)" in p.stdout
+    p = subprocess.run([SWIMM, "-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-x", "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert p.returncode == 5 and "4 GPUs requested, 3 visible" in p.stdout

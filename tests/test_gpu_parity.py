@@ -125,6 +125,21 @@ def test_search_chunks_dropin(tmp_path, golden):
     assert np.array_equal(sc[:, :N], load_npy("scores_blosum62_g10_e2.npy")) and wt > 0
 
 
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_search_chunks_shards_over_devices(tmp_path, golden, monkeypatch, gpus):
+    """the multi-GPU host path of the drop-in call (static shard, one thread and one context per device, scatter into
+    one score array) on the one-GPU test box: SWIMM_HIP_VIRTUAL_GPUS maps device d to physical device d % 1"""
+    monkeypatch.setenv("SWIMM_HIP_VIRTUAL_GPUS", str(gpus))
+    assert hip_backend.device_count() == gpus
+    q, pp, chunked = golden_inputs(tmp_path, golden, vl=32, max_chunk=12000)
+    assert len(chunked["chunks"]) >= gpus
+    N = golden["search"]["n_sequences"]
+    sc, wt = hip_backend.search_chunks(q["a"], q["m"], q["disp"], chunked["vc"], chunked["chunks"], matrix("blosum62"), 10, 2, gpus, 32)
+    assert np.array_equal(sc[:, :N], load_npy("scores_blosum62_g10_e2.npy"))
+    with pytest.raises(hip_backend.SwimmHipError):
+        hip_backend.search_chunks(q["a"], q["m"], q["disp"], chunked["vc"], chunked["chunks"], matrix("blosum62"), 10, 2, gpus + 1, 32)
+
+
 def test_errors_are_loud():
     with hip_backend.HipSearcher(0) as s:
         with pytest.raises(hip_backend.SwimmHipError):

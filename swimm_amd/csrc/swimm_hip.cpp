@@ -673,7 +673,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         c->queue_next = 0;
         if (reserve_lane_scratch(c->tail_scratch, tail_cols, tail_items, max_passes)) return 1;
         if (reserve_lane_scratch(c->rerun_scratch, (size_t)1 << 22, 4096, max_passes)) return 1;
-        HIP_TRY(c->d_satlist.reserve((size_t)(1u << 16) + 1));
+        HIP_TRY(c->d_satlist.reserve((size_t)std::min<uint64_t>(S, 0xFFFFFFFEull) + 1));   // every slot could leave a tier's range
         HIP_TRY(c->d_rerun_items.reserve(4096));
     }
     HIP_TRY(c->d_err.reserve(1));
@@ -712,7 +712,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     // re-run is a lane-systolic item (one wave per alignment), issued on stream 3 as soon as the query's own
     // kernels are done
     if (main_mode != Mode::I32) {
-        const uint32_t cap = 1u << 16;
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(S, 0xFFFFFFFEull);   // list capacity = all slots: no query can overflow it
         std::vector<uint32_t> list;
         auto collect = [&](uint32_t q, int thr, std::vector<uint32_t> &out) -> int {
             int32_t *row = c->d_scores.p + (size_t)q * S;

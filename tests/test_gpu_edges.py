@@ -117,3 +117,37 @@ def test_every_strip_height_vs_oracle(T):
     for W in (1, 3, 4):
         run_case(seqs, queries, opts={"rows_per_wave": T, "waves": W, "tail_mode": 2})
     run_case(seqs, queries, opts={"rows_per_wave": T})
+
+
+def test_mass_promotion():
+    """a family of 66 000 near-copies of the query: every alignment leaves the binary16 range (>= 2048), more than
+    any fixed-size list would hold; plus 40 W-runs that also leave int16.  All of them come back exact."""
+    rng = np.random.default_rng(77)
+    base = rnd(rng, 450)
+    fam = np.tile(base, (66000, 1))
+    pos = rng.integers(0, 450, 66000)
+    fam[np.arange(66000), pos] = rng.integers(0, 20, 66000)          # one substitution each
+    seqs = [fam[i] for i in range(66000)]
+    seqs += [np.full(int(n), CODE["W"], np.int8) for n in rng.integers(3000, 3100, 40)]
+    wq = np.full(3080, CODE["W"], np.int8)
+    seqs = sorted(seqs, key=len)
+    lens = np.array([len(s) for s in seqs], dtype=np.uint16)
+    codes = np.concatenate(seqs).astype(np.int8)
+    queries = [base, wq]
+    m = np.array([len(q) for q in queries], dtype=np.uint16)
+    disp = np.concatenate([[0], np.cumsum(m)]).astype(np.uint32)
+    a = np.concatenate(queries).astype(np.int8)
+    sm = submat.table("blosum62")
+    ch = host.Chunks(lens, codes, 128, 8 << 20)
+    with hip_backend.HipSearcher(0) as s:
+        s.set_queries(a, m, disp, sm, 10, 2)
+        for c in ch.chunks:
+            s.add_chunk(c["b"], c["n"], c["disp"], 128, c["first_group"])
+        got, _ = s.search(ch.vc * 128)
+        st = s.last_stats()
+    one = port.assemble_single_chunk(lens, codes, 128, 5)
+    want = port.search_exact(a, m, disp, one["b"], one["n"], one["disp"], sm, 10, 2, 128)
+    ch.close()
+    n = len(seqs)
+    assert np.array_equal(got[:, :n], want[:, :n])
+    assert (want[0, :n] >= 2048).sum() > 65536 and st["promoted"] >= 40

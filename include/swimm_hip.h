@@ -70,6 +70,13 @@ int swimm_hip_set_queries(swimm_hip_ctx *ctx, const char *a, const uint16_t *m, 
 int swimm_hip_add_chunk(swimm_hip_ctx *ctx, const char *b, uint64_t vD, const uint16_t *n,
                         const uint32_t *b_disp, uint32_t group_count, uint32_t vl, uint64_t first_group);
 
+/* The same database content without the host-side lane interleave: `n_seq` consecutive sequences of the sorted
+ * database exactly as the .seq file stores them (sequences.c:201-205) -- `lengths[i]` residues each, codes
+ * concatenated -- starting at sorted index `first_seq`.  Replaces assemble_multiple_chunks_db (sequences.c:425-616)
+ * + the copy above for a caller that has the preprocessed database in memory: the device builds its layout itself.
+ * A slab must stay below 4 GiB of residues; every slab but the last must hold a multiple of 128 sequences. */
+int swimm_hip_add_sequences(swimm_hip_ctx *ctx, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq);
+
 int swimm_hip_clear_db(swimm_hip_ctx *ctx);
 
 /* The search itself (kernels K2-K5 + score scatter X3, MICsearch.c:91-334; same result as

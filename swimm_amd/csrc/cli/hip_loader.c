@@ -48,6 +48,7 @@ int swimm_hip_load(swimm_hip_api *api, char *err, unsigned long err_len)
     BIND(destroy, "swimm_hip_destroy");
     BIND(set_queries, "swimm_hip_set_queries");
     BIND(add_chunk, "swimm_hip_add_chunk");
+    BIND(add_sequences, "swimm_hip_add_sequences");
     BIND(clear_db, "swimm_hip_clear_db");
     BIND(search, "swimm_hip_search");
     BIND(search_topr, "swimm_hip_search_topr");

@@ -13,6 +13,7 @@ typedef struct {
     void (*destroy)(swimm_hip_ctx *);
     int (*set_queries)(swimm_hip_ctx *, const char *, const uint16_t *, const uint32_t *, uint32_t, const char *, int, int);
     int (*add_chunk)(swimm_hip_ctx *, const char *, uint64_t, const uint16_t *, const uint32_t *, uint32_t, uint32_t, uint64_t);
+    int (*add_sequences)(swimm_hip_ctx *, const uint16_t *, const char *, uint64_t, uint64_t);
     int (*clear_db)(swimm_hip_ctx *);
     int (*search)(swimm_hip_ctx *, int32_t *, uint64_t, double *);
     int (*search_topr)(swimm_hip_ctx *, uint32_t, uint64_t, int32_t *, int64_t *, double *);

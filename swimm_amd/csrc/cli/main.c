@@ -40,23 +40,50 @@ static int do_preprocess(const swimm_options *o)
     return 0;
 }
 
-/* static shard: chunks longest-first onto the least-loaded GPU (cost = padded bytes) */
-static void shard_chunks(const swimm_chunks *ch, int gpus, int *owner)
+/* A slab = a run of consecutive sequences of the sorted database that goes to one GPU in one piece: the
+ * counterpart of the reference's chunks (sequences.c:533-557: greedy, a chunk may exceed max_chunk_size by one lane
+ * group), cut at multiples of 128 sequences.  The residues travel as the .seq file stores them; the device builds
+ * its own layout (swimm_hip_add_sequences), so no host-side interleave is needed for the GPU modes. */
+typedef struct { uint64_t first, count, residues, offset; int owner; } slab_t;
+
+static slab_t *make_slabs(const uint16_t *lengths, uint64_t count, uint64_t max_bytes, uint32_t *n_out)
+{
+    uint32_t cap = 16, n = 0;
+    slab_t *v = (slab_t *)malloc(cap * sizeof(slab_t));
+    uint64_t i = 0, offset = 0;
+    if (max_bytes > 0xE0000000ull) max_bytes = 0xE0000000ull;       /* a slab stays below 4 GiB */
+    while (i < count) {
+        slab_t sl = {i, 0, 0, offset, 0};
+        while (i < count && (sl.count == 0 || sl.residues <= max_bytes)) {
+            const uint64_t e = i + 128 < count ? i + 128 : count;
+            for (; i < e; ++i) sl.residues += lengths[i];
+            sl.count = i - sl.first;
+        }
+        offset += sl.residues;
+        if (n == cap) { cap *= 2; v = (slab_t *)realloc(v, cap * sizeof(slab_t)); }
+        v[n++] = sl;
+    }
+    *n_out = n;
+    return v;
+}
+
+/* static shard: slabs longest-first onto the least-loaded GPU (cost = residues) */
+static void shard_slabs(slab_t *v, uint32_t n, int gpus)
 {
     uint64_t *load = (uint64_t *)calloc((size_t)gpus, sizeof(uint64_t));
-    uint32_t *order = (uint32_t *)malloc(ch->chunk_count * sizeof(uint32_t));
-    for (uint32_t i = 0; i < ch->chunk_count; ++i) order[i] = i;
-    for (uint32_t i = 1; i < ch->chunk_count; ++i) {   /* insertion sort, stable, descending vD */
+    uint32_t *order = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    for (uint32_t i = 1; i < n; ++i) {   /* insertion sort, stable, descending size */
         uint32_t x = order[i];
         int64_t j = (int64_t)i - 1;
-        while (j >= 0 && ch->chunk_vD[order[j]] < ch->chunk_vD[x]) { order[j + 1] = order[j]; --j; }
+        while (j >= 0 && v[order[j]].residues < v[x].residues) { order[j + 1] = order[j]; --j; }
         order[j + 1] = x;
     }
-    for (uint32_t k = 0; k < ch->chunk_count; ++k) {
+    for (uint32_t k = 0; k < n; ++k) {
         int best = 0;
         for (int g = 1; g < gpus; ++g) if (load[g] < load[best]) best = g;
-        owner[order[k]] = best;
-        load[best] += ch->chunk_vD[order[k]];
+        v[order[k]].owner = best;
+        load[best] += v[order[k]].residues;
     }
     free(load);
     free(order);
@@ -81,19 +108,19 @@ static void cpu_leg(const swimm_options *o, const swimm_queries *q, const char *
     free(scores);
 }
 
-/* GPU leg: the chunks `ch` (assembled by the caller from `count` sequences of the sorted database starting at
- * sequence `first`) dealt to o->num_gpus devices; per device and query the first `top` rows, lists laid out
+/* GPU leg: `count` sequences of the sorted database starting at sequence `first` (lengths / codes point at them),
+ * cut into slabs and dealt to o->num_gpus devices; per device and query the first `top` rows, lists laid out
  * [device][query][top], indices global. */
 static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swimm_queries *q, const char *submat,
-                    const swimm_chunks *chp, uint64_t count, uint64_t first, unsigned long top,
+                    const uint16_t *lengths, const char *codes, uint64_t count, uint64_t first, unsigned long top,
                     int32_t *part_s, int64_t *part_i, leg_stats *st)
 {
     const double tick = swimm_wtime();
     const int G = o->num_gpus;
-    const swimm_chunks ch = *chp;
-    st->chunk_count = ch.chunk_count;
-    int *owner = (int *)malloc(ch.chunk_count * sizeof(int));
-    shard_chunks(&ch, G, owner);
+    uint32_t n_slabs = 0;
+    slab_t *slabs = make_slabs(lengths, count, (uint64_t)o->max_chunk_size, &n_slabs);
+    shard_slabs(slabs, n_slabs, G);
+    st->chunk_count = n_slabs;
     char (*gerr)[512] = calloc((size_t)G, 512);
     double *g_kms = (double *)calloc((size_t)G, sizeof(double));
     uint64_t *g_prom = (uint64_t *)calloc((size_t)G, sizeof(uint64_t));
@@ -102,16 +129,16 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
         const int g = omp_get_thread_num();
         swimm_hip_ctx *ctx = NULL;
         int mine = 0;
-        for (uint32_t c = 0; c < ch.chunk_count; ++c) mine += owner[c] == g;
+        for (uint32_t c = 0; c < n_slabs; ++c) mine += slabs[c].owner == g;
         int bad = 0;
         if (mine == 0) bad = -1;   /* nothing to do on this device */
         const double t0 = swimm_wtime();
         if (!bad && api->create(g, &ctx)) bad = 1;
         const double t1 = swimm_wtime();
         if (!bad && api->set_queries(ctx, q->a, q->m, q->disp, (uint32_t)q->count, submat, o->open_gap, o->extend_gap)) bad = 1;
-        for (uint32_t c = 0; !bad && c < ch.chunk_count; ++c)
-            if (owner[c] == g && api->add_chunk(ctx, ch.chunk_b[c], ch.chunk_vD[c], ch.chunk_n[c], ch.chunk_disp[c],
-                                                ch.chunk_groups[c], 128, ch.chunk_first_group[c])) bad = 1;
+        for (uint32_t c = 0; !bad && c < n_slabs; ++c)
+            if (slabs[c].owner == g && api->add_sequences(ctx, lengths + slabs[c].first, codes + slabs[c].offset, slabs[c].count,
+                                                          slabs[c].first)) bad = 1;
         const double t2 = swimm_wtime();
         int32_t *ps = part_s + (size_t)g * q->count * top;
         int64_t *pi = part_i + (size_t)g * q->count * top;
@@ -127,7 +154,7 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
     }
     for (int g = 0; g < G; ++g) if (gerr[g][0]) { printf("SWIMM: GPU %d: %s\n", g, gerr[g]); exit(5); }
     for (int g = 0; g < G; ++g) { if (g_kms[g] > st->kernel_ms) st->kernel_ms = g_kms[g]; st->promoted += g_prom[g]; }
-    free(gerr); free(g_kms); free(g_prom); free(owner);
+    free(gerr); free(g_kms); free(g_prom); free(slabs);
     st->seconds = swimm_wtime() - tick;
 }
 
@@ -236,21 +263,18 @@ int main(int argc, char **argv)
         int64_t *part_i = (int64_t *)malloc((size_t)lists * q.count * top * sizeof(int64_t));
         if (!part_s || !part_i) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
         for (size_t i = 0; i < (size_t)lists * q.count * top; ++i) { part_s[i] = -1; part_i[i] = -1; }
-        swimm_chunks ch;            /* both layouts are built before the clock starts (swimm.c:46 precedes the search call) */
-        swimm_single_chunk sc;
-        if ((rc = swimm_assemble_chunks(db.lengths + n_cpu, db.codes + cpu_residues, n_gpu, 128, o.max_chunk_size, &ch))) die_host(rc);
+        swimm_single_chunk sc;      /* the host's lane layout is built before the clock starts (swimm.c:46 precedes the search call) */
         if (n_cpu && (rc = swimm_assemble_single_chunk(db.lengths, db.codes, n_cpu, o.vector_length, o.cpu_block_size, &sc))) die_host(rc);
         const double tick = swimm_wtime();   /* brackets transfers + kernels + merge, like MICsearch.c:51,350 */
         omp_set_max_active_levels(2);
 #pragma omp parallel sections num_threads(2)
         {
 #pragma omp section
-            gpu_leg(&api, &o, &q, submat, &ch, n_gpu, n_cpu, top, part_s, part_i, &gst);
+            gpu_leg(&api, &o, &q, submat, db.lengths + n_cpu, db.codes + cpu_residues, n_gpu, n_cpu, top, part_s, part_i, &gst);
 #pragma omp section
             if (n_cpu) cpu_leg(&o, &q, submat, &sc, n_cpu, top, part_s + (size_t)G * q.count * top,
                                part_i + (size_t)G * q.count * top, &cst);
         }
-        swimm_chunks_free(&ch);
         if (n_cpu) swimm_single_chunk_free(&sc);
         /* host k-way merge of the per-device lists ([lists][query][top]) */
         int32_t *ls = (int32_t *)malloc((size_t)lists * top * sizeof(int32_t));

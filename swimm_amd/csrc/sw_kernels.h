@@ -94,6 +94,10 @@ hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *di
                          const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled,
                          uint32_t *seq_len /* [dev_groups*128], zeroed; gets every sequence's true length */, hipStream_t s);
 
+// Tile a slab of sorted sequences (concatenated codes + offsets, as in the .seq file) into device groups directly.
+hipError_t launch_tile_sequences(const uint8_t *codes, const uint32_t *seq_off /* [n_seq + 1] */, uint32_t n_seq, const uint64_t *goff,
+                                 const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled, hipStream_t s);
+
 // appends the slots whose score is >= thr (tier left its exact range) to list (up to cap) and zeroes them
 hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, int thr, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s);
 // per-block top-64 candidates of one query's score row: out_keys[block*64 + i] = ((score<<32 | global index) + 1),

@@ -851,6 +851,49 @@ hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *di
     return hipGetLastError();
 }
 
+// ---- tile: sorted sequences as stored in the .seq file -> device groups ----------------------------
+// The direct path of the `swimm` program: the concatenated residue codes and their offsets go to the GPU as they
+// are and the device builds its own layout, instead of the host interleaving lanes first (sequences.c:506-526)
+// and retile_kernel undoing it.  Group g holds sequences 128 g .. 128 g + 127 of the slab; lane l of chunk c gets
+// columns 4c..4c+3 of sequence l (low dword) and of sequence 64 + l (high dword), code 24 past a sequence's end.
+__global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const uint32_t *__restrict__ seq_off, uint32_t n_seq,
+                                      const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols,
+                                      uint8_t *__restrict__ tiled)
+{
+    const uint32_t g = blockIdx.x;
+    const uint32_t nch = gcols[g] / kChunkCols;
+    for (uint32_t idx = threadIdx.x; idx < nch * 64; idx += blockDim.x) {
+        const uint32_t c = idx >> 6, l = idx & 63;
+        uint32_t w[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const uint32_t s = g * kGroupSeqs + l + 64 * hh;
+            uint32_t word = 0x18181818u;              // four padding codes (24)
+            if (s < n_seq) {
+                const uint32_t b0 = seq_off[s], len = seq_off[s + 1] - b0;
+                word = 0;
+#pragma unroll
+                for (int jj = 0; jj < kChunkCols; ++jj) {
+                    const uint32_t col = c * kChunkCols + jj;
+                    uint32_t code = 24;
+                    if (col < len) { code = codes[(size_t)b0 + col]; if (code > 24) code = 24; }
+                    word |= code << (8 * jj);
+                }
+            }
+            w[hh] = word;
+        }
+        *(uint2 *)(tiled + goff[g] + (size_t)idx * 8) = make_uint2(w[0], w[1]);
+    }
+}
+
+hipError_t launch_tile_sequences(const uint8_t *codes, const uint32_t *seq_off, uint32_t n_seq, const uint64_t *goff,
+                                 const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled, hipStream_t s)
+{
+    if (dev_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_sequences_kernel, dim3(dev_groups), dim3(256), 0, s, codes, seq_off, n_seq, goff, gcols, tiled);
+    return hipGetLastError();
+}
+
 // ---- saturation bookkeeping ----------------------------------------------------------------
 // list[i] = slots whose first-tier best left the tier's exact range (>= thr: 32767 for int16, CPUsearch.c:820-824
 // "overflow detection"; 2048 for f16);

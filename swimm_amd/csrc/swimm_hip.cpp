@@ -978,6 +978,70 @@ int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint
     return 0;
 }
 
+int swimm_hip_add_sequences(swimm_hip_ctx *c, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq)
+{
+    if (!c || !lengths || !codes) return fail("swimm_hip_add_sequences: NULL argument");
+    if (n_seq == 0) return fail("swimm_hip_add_sequences: empty slab");
+    if (n_seq > 0x7FFFFFFFull) return fail("swimm_hip_add_sequences: more than 2^31 sequences in one slab");
+    std::vector<uint32_t> off(n_seq + 1);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n_seq; ++i) { off[i] = (uint32_t)total; total += lengths[i]; if (total > 0xFFFFFFF0ull) return fail("swimm_hip_add_sequences: slab larger than 4 GiB"); }
+    off[n_seq] = (uint32_t)total;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t dev_groups = (uint32_t)((n_seq + kGroupSeqs - 1) / kGroupSeqs);
+    std::vector<uint64_t> goff(dev_groups);
+    std::vector<uint32_t> gcols(dev_groups);
+    uint64_t bytes = 0;
+    for (uint32_t g = 0; g < dev_groups; ++g) {
+        uint32_t mx = 1;
+        const uint64_t e = std::min<uint64_t>(n_seq, (uint64_t)(g + 1) * kGroupSeqs);
+        for (uint64_t i = (uint64_t)g * kGroupSeqs; i < e; ++i) mx = std::max<uint32_t>(mx, lengths[i]);
+        gcols[g] = (mx + kChunkCols - 1) / kChunkCols * kChunkCols;
+        goff[g] = bytes;
+        bytes += (uint64_t)gcols[g] * kGroupSeqs;
+    }
+    uint8_t *d_codes = nullptr, *d_tiled = nullptr;
+    uint32_t *d_off = nullptr, *d_gcols = nullptr;
+    uint64_t *d_goff = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_codes); (void)hipFree(d_off); (void)hipFree(d_gcols); (void)hipFree(d_goff); };
+#define TRY_OR_CLEAN(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); (void)hipFree(d_tiled); return fail("%s: %s", #expr, hipGetErrorString(e__)); } } while (0)
+    TRY_OR_CLEAN(hipMalloc((void **)&d_codes, std::max<uint64_t>(total, 1)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_off, off.size() * sizeof(uint32_t)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_gcols, dev_groups * sizeof(uint32_t)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_goff, dev_groups * sizeof(uint64_t)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_tiled, bytes));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_codes, codes, total, hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_gcols, gcols.data(), dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_goff, goff.data(), dev_groups * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(launch_tile_sequences(d_codes, d_off, (uint32_t)n_seq, d_goff, d_gcols, dev_groups, d_tiled, c->stream));
+    TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
+#undef TRY_OR_CLEAN
+    cleanup();
+    ChunkRec rec;
+    rec.d_tiled = d_tiled;
+    rec.first_seq = first_seq;
+    rec.n_seq = n_seq;
+    rec.group0 = (uint32_t)c->groups.size();
+    rec.n_groups = dev_groups;
+    for (uint32_t g = 0; g < dev_groups; ++g) {
+        GroupDesc gd;
+        gd.db = d_tiled + goff[g];
+        gd.ncols = gcols[g];
+        gd.seq0 = (uint32_t)((rec.group0 + g) * kGroupSeqs);
+        c->groups.push_back(gd);
+        c->group_col_off.push_back(c->total_cols);
+        c->total_cols += gcols[g];
+    }
+    const size_t base = c->seq_len.size();
+    c->seq_len.resize(base + (size_t)dev_groups * kGroupSeqs, 0);
+    for (uint64_t i = 0; i < n_seq; ++i) c->seq_len[base + i] = lengths[i];
+    c->chunks.push_back(rec);
+    c->groups_dirty = true;
+    release_plans(c);
+    return 0;
+}
+
 int swimm_hip_clear_db(swimm_hip_ctx *c)
 {
     if (!c) return fail("swimm_hip_clear_db: NULL ctx");

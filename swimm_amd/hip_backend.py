@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("SWIMM_HIP_LIB") or os.path.join(_HERE, "lib", "libswi
 # every symbol include/swimm_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = (
     "swimm_hip_abi_version", "swimm_hip_last_error", "swimm_hip_device_count", "swimm_hip_create",
-    "swimm_hip_destroy", "swimm_hip_set_queries", "swimm_hip_add_chunk", "swimm_hip_clear_db",
+    "swimm_hip_destroy", "swimm_hip_set_queries", "swimm_hip_add_chunk", "swimm_hip_add_sequences", "swimm_hip_clear_db",
     "swimm_hip_search", "swimm_hip_search_topr", "swimm_hip_last_stats", "swimm_hip_last_plan", "swimm_hip_set_option",
     "swimm_hip_search_chunks",
 )
@@ -113,6 +113,14 @@ class HipSearcher:
         b_disp = np.ascontiguousarray(b_disp, dtype=np.uint32)
         _check(self._L.swimm_hip_add_chunk(self._ctx, _p(b), C.c_uint64(b.size), _p(n), _p(b_disp), C.c_uint32(len(n)),
                                            C.c_uint32(vl), C.c_uint64(first_group)))
+
+    def add_sequences(self, lengths, codes, first_seq: int = 0):
+        """sorted sequences as the .seq file stores them (lengths + concatenated codes): tiled on the device"""
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint16)
+        codes = np.ascontiguousarray(codes, dtype=np.int8)
+        if int(lengths.astype(np.int64).sum()) != codes.size:
+            raise ValueError("lengths do not add up to the number of codes")
+        _check(self._L.swimm_hip_add_sequences(self._ctx, _p(lengths), _p(codes), C.c_uint64(len(lengths)), C.c_uint64(first_seq)))
 
     def clear_db(self):
         _check(self._L.swimm_hip_clear_db(self._ctx))

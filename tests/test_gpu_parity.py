@@ -125,6 +125,30 @@ def test_search_chunks_dropin(tmp_path, golden):
     assert np.array_equal(sc[:, :N], load_npy("scores_blosum62_g10_e2.npy")) and wt > 0
 
 
+@pytest.mark.parametrize("cut", [None, 128, 256, 384])
+def test_add_sequences_direct_path(searcher, gin, golden, cut):
+    """the .seq content (lengths + concatenated codes) tiled on the device, in one slab or two: same scores as the
+    reference chunk layout"""
+    q, pp, chunked = gin
+    N = golden["search"]["n_sequences"]
+    lens, codes = pp["lengths"], pp["codes"]
+    searcher.clear_db()
+    searcher.set_queries(q["a"], q["m"], q["disp"], matrix("blosum62"), 10, 2)
+    if cut is None:
+        searcher.add_sequences(lens, codes, 0)
+    else:
+        r = int(lens[:cut].astype(np.int64).sum())
+        searcher.add_sequences(lens[:cut], codes[:r], 0)
+        searcher.add_sequences(lens[cut:], codes[r:], cut)
+    stride = (N + 127) // 128 * 128 + 128
+    sc, _ = searcher.search(stride)
+    assert np.array_equal(sc[:, :N], load_npy("scores_blosum62_g10_e2.npy"))
+    ts, ti, _ = searcher.search_topr(30, N)
+    for qi in range(sc.shape[0]):
+        s, i = port.topr(sc[qi, :N], 30)
+        assert np.array_equal(ts[qi], s) and np.array_equal(ti[qi], i)
+
+
 @pytest.mark.parametrize("gpus", [2, 3])
 def test_search_chunks_shards_over_devices(tmp_path, golden, monkeypatch, gpus):
     """the multi-GPU host path of the drop-in call (static shard, one thread and one context per device, scatter into

@@ -144,11 +144,24 @@ def test_against_reference_fresh_inputs(tmp_path, oracle_built):
     port.preprocess(dbfa, str(tmp_path / "p"))
     assert open(str(tmp_path / "r.seq"), "rb").read() == open(str(tmp_path / "p.seq"), "rb").read()
     assert open(str(tmp_path / "r.info"), "rb").read() == open(str(tmp_path / "p.info"), "rb").read()
-    rl = open(str(tmp_path / "r.desc"), "rb").read().split(b"\n")
+    # the reference leaves one uninitialised byte after each title -- which can itself be a newline -- so the two files
+    # are walked title by title instead of being split into lines
+    rd = open(str(tmp_path / "r.desc"), "rb").read()
     pl = open(str(tmp_path / "p.desc"), "rb").read().split(b"\n")
-    assert len(rl) == len(pl)
-    for x, y in zip(rl, pl):  # reference leaves one uninitialised byte after each title
-        assert x == y or x[:-1] == y
+    pos = 0
+    for y in pl:
+        if not y:
+            continue
+        assert rd[pos:pos + len(y)] == y, y
+        pos += len(y)
+        if rd[pos:pos + 2] == b"\n\n":
+            pos += 2                                   # the stray byte happens to be a newline
+        elif rd[pos:pos + 1] == b"\n":
+            pos += 1                                   # no stray byte
+        else:
+            assert rd[pos + 1:pos + 2] == b"\n"
+            pos += 2                                   # stray byte, then the newline
+    assert pos == len(rd)
     rq, pq = ref.load_queries(qfa, 0, 2), port.load_queries(qfa, 0)
     for k in ("a", "m", "lengths", "disp"):
         assert np.array_equal(rq[k], pq[k]), k

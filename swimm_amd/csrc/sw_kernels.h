@@ -18,17 +18,18 @@ struct GroupDesc {
     uint32_t seq0;       // local score slot of lane 0 (half A); half B starts at seq0 + 64
 };
 
-// One unit of work for a workgroup's pipeline.
+// One unit of work for a workgroup's pipeline: self-contained (32 bytes, one scalar load), so that starting a group
+// does not cost two dependent global loads (item -> group descriptor).
 struct Item {
-    uint32_t group;      // index into GroupDesc[]
-    uint32_t half;       // int32 mode only: 0 = sequences 0..63 of the group, 1 = 64..127
-    uint32_t out_slot;   // int32 mode only: results go to out[out_slot*64 + lane]
-    uint32_t pad_;
+    const uint8_t *db;   // tiled residues of the group
+    uint32_t ncols;      // padded length, multiple of kChunkCols
+    uint32_t seq0;       // packed tiers: local score slot of lane 0 (half A); half B starts at seq0 + 64
+    uint32_t half;       // int32 tier only: 0 = sequences 0..63 of the group, 1 = 64..127
+    uint32_t out_slot;   // int32 tier only: results go to out[out_slot*64 + lane]
     uint64_t bnd_off;    // first column of this item in the pass-boundary buffer
 };
 
 struct PipeParams {
-    const GroupDesc *groups;
     const Item *items;
     const uint32_t *wg_first;   // static partition: [n_wg + 1] item ranges
     const uint32_t *wg_chunks;  // static partition: [n_wg] total column chunks per workgroup

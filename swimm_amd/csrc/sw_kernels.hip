@@ -163,6 +163,20 @@ size_t pipe_lds_bytes(int T, int W)
 
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 
+// an item descriptor through the constant address space: the index is wave-uniform and the list is read-only for the
+// whole launch, so this is one s_load_dwordx8 into scalar registers
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+static_assert(sizeof(Item) == 32, "Item is loaded as eight dwords");
+__device__ __forceinline__ Item load_item(const Item *items, uint32_t idx)
+{
+    const u32x8 r = *(const __attribute__((address_space(4))) u32x8 *)(uintptr_t)(items + idx);
+    Item it;
+    it.db = (const uint8_t *)(uintptr_t)(((uint64_t)r[1] << 32) | r[0]);
+    it.ncols = r[2]; it.seq0 = r[3]; it.half = r[4]; it.out_slot = r[5];
+    it.bnd_off = ((uint64_t)r[7] << 32) | r[6];
+    return it;
+}
+
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t x)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
@@ -286,12 +300,11 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
         STAMP(tA);
         if (c >= 0 && it != kNoItem) {            // wave-uniform
             if (cc == 0) {                        // first chunk of a new item: reset the DP state
-                // the item is the same for the whole wave: keep its descriptor in scalar registers
-                const Item iv = p.items[__builtin_amdgcn_readfirstlane(it)];
-                const GroupDesc g = p.groups[__builtin_amdgcn_readfirstlane(iv.group)];
-                nch = __builtin_amdgcn_readfirstlane(g.ncols / C); dbp = uniform_ptr(g.db); seq0 = __builtin_amdgcn_readfirstlane(g.seq0);
-                half = __builtin_amdgcn_readfirstlane(iv.half); out_slot = __builtin_amdgcn_readfirstlane(iv.out_slot);
-                bnd_off = uniform_u64(iv.bnd_off);
+                // the item is the same for the whole wave: one scalar load, descriptor in scalar registers
+                const Item iv = load_item(p.items, __builtin_amdgcn_readfirstlane(it));
+                nch = iv.ncols / C; dbp = iv.db; seq0 = iv.seq0;
+                half = iv.half; out_slot = iv.out_slot;
+                bnd_off = iv.bnd_off;
                 best = Ops::zero(); diag_top = Ops::zero();
 #pragma unroll
                 for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
@@ -324,8 +337,8 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         next_it = it + 1 < it_end ? it + 1 : kNoItem;
                     }
                     if (next_it != kNoItem) {
-                        const Item niv = p.items[next_it];
-                        ndb = uniform_ptr(p.groups[__builtin_amdgcn_readfirstlane(niv.group)].db); ncc = 0; nhalf = __builtin_amdgcn_readfirstlane(niv.half);
+                        const Item niv = load_item(p.items, next_it);
+                        ndb = niv.db; ncc = 0; nhalf = niv.half;
                     } else {
                         have_next = false;
                     }

@@ -314,7 +314,8 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
         first[w] = (uint32_t)items.size();
         for (uint32_t idx : bins[w]) {
             const WorkUnit &u = units[idx];
-            Item it{}; it.group = u.group; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = u.bnd_off;
+            const GroupDesc &gd = c->groups[u.group];
+            Item it{}; it.db = gd.db; it.ncols = gd.ncols; it.seq0 = gd.seq0; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = u.bnd_off;
             items.push_back(it);
         }
         chunks[w] = (uint32_t)(load[w] / kChunkCols);
@@ -328,7 +329,8 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
     uint64_t before = 0;
     for (uint32_t idx : order) {
         const WorkUnit &u = units[idx];
-        Item it{}; it.group = u.group; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = before;
+        const GroupDesc &gd = c->groups[u.group];
+        Item it{}; it.db = gd.db; it.ncols = gd.ncols; it.seq0 = gd.seq0; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = before;
         before += u.ncols;
         sorted.push_back(it);
         pl.queue_cols.push_back(u.ncols);
@@ -431,7 +433,6 @@ int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, DbPlan **out)
 
 void fill_common(const swimm_hip_ctx *c, const QueryPlan &qp, PipeParams &p)
 {
-    p.groups = c->d_groups.p;
     p.prof = c->d_prof.p + qp.prof_off;
     p.prof_stride = qp.mpad;
     p.bnd = c->d_bnd.p;

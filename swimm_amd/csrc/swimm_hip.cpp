@@ -147,7 +147,6 @@ struct swimm_hip_ctx {
     std::vector<uint64_t> group_col_off;
     std::vector<uint32_t> seq_len;      // true length of every local slot (from the re-tile kernel)
     uint64_t total_cols = 0;
-    DevBuf<GroupDesc> d_groups;
     bool groups_dirty = true;
     std::map<int, DbPlan> plans;        // key: n_wg (packed mode), n_wg | 1<<30 (whole-db int32 mode)
     // scratch
@@ -579,26 +578,24 @@ int reserve_lane_scratch(LaneScratch &sc, size_t cols, size_t items, int passes)
     return 0;
 }
 
-int upload_groups(swimm_hip_ctx *c)
+// the work lists are derived from the resident database: rebuild them after it changed
+int refresh_plans(swimm_hip_ctx *c)
 {
     if (!c->groups_dirty) return 0;
-    HIP_TRY(c->d_groups.reserve(c->groups.size()));
-    HIP_TRY(hipMemcpyAsync(c->d_groups.p, c->groups.data(), c->groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     release_plans(c);
     c->groups_dirty = false;
     return 0;
 }
 
 // device part of a search for the queries [qb, qe) (ascending-length order of set_queries): leaves exact scores in
-// d_scores[(q - qb) * S + local_slot].  The callers walk the query list in batches whose score rows fit
-// kScoreBudgetBytes of HBM.
+// d_scores[(q - qb) * S + local_slot].  The callers walk the query list in batches whose score rows fit the
+// `score_mib` budget.
 int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_out)
 {
     if (!c->have_queries) return fail("swimm_hip_search: no queries set");
     if (c->groups.empty()) return fail("swimm_hip_search: no database chunk resident");
     HIP_TRY(hipSetDevice(c->device));
-    if (upload_groups(c)) return 1;
+    if (refresh_plans(c)) return 1;
     const uint32_t qn = qe - qb;
     const uint16_t *qm = c->qm.data() + qb;
     const uint32_t *qdisp = c->qdisp.data() + qb;
@@ -869,7 +866,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
-    c->d_groups.release(); c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
+    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

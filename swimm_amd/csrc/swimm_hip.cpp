@@ -70,10 +70,13 @@ struct Plan {      // static partition of a work list over n_wg persistent workg
     DevBuf<uint32_t> wg_first, wg_chunks;
     DevBuf<Item> queue_items;    // the same items sorted longest first (dynamic queue); bnd_off = columns before the item in this order
     std::vector<uint32_t> queue_cols;   // their column counts (host copy, for cutting the list into boundary-buffer segments)
+    DevBuf<Item> split_items;    // the even-ranked items of that list followed by the odd-ranked ones (two-stream launches)
+    uint32_t split_n[2] = {0, 0};
+    uint64_t split_cols[2] = {0, 0};
     uint32_t n_items = 0;
     uint64_t bnd_cols = 0;   // columns the pass-boundary buffer must hold
     uint64_t max_wg_chunks = 0, total_chunks = 0;
-    void release() { items.release(); wg_first.release(); wg_chunks.release(); queue_items.release(); }
+    void release() { items.release(); wg_first.release(); wg_chunks.release(); queue_items.release(); split_items.release(); }
 };
 
 // lane-systolic work list (long-sequence tail, int32 promotion): items sorted longest first, pulled
@@ -113,6 +116,8 @@ struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; };
 struct swimm_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_b = nullptr;     // second bulk stream: multi-pass queries run the two halves of the group list side by side
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     hipStream_t stream2 = nullptr;      // lane-systolic tail runs beside the bulk kernel
     hipEvent_t ev_tail = nullptr;
     hipStream_t stream3 = nullptr;      // promotion re-runs
@@ -127,6 +132,7 @@ struct swimm_hip_ctx {
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
     int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
     int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
+    int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
     int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
     int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
     // caches that depend on the resident database / the code objects
@@ -335,6 +341,24 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
         pl.queue_cols.push_back(u.ncols);
     }
     pl.n_items = (uint32_t)sorted.size();
+    {   // the same list as two interleaved halves, each sorted longest first, boundary offsets counted along this order
+        std::vector<Item> split; split.reserve(sorted.size());
+        uint64_t off = 0;
+        for (int h = 0; h < 2; ++h) {
+            pl.split_n[h] = 0; pl.split_cols[h] = 0;
+            for (size_t i = (size_t)h; i < sorted.size(); i += 2) {
+                Item it = sorted[i];
+                it.bnd_off = off;
+                off += pl.queue_cols[i];
+                pl.split_cols[h] += pl.queue_cols[i];
+                pl.split_n[h]++;
+                split.push_back(it);
+            }
+        }
+        HIP_TRY(pl.split_items.reserve(split.size()));
+        HIP_TRY(hipMemcpyAsync(pl.split_items.p, split.data(), split.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // `split` dies here
+    }
     HIP_TRY(pl.queue_items.reserve(sorted.size()));
     HIP_TRY(hipMemcpyAsync(pl.queue_items.p, sorted.data(), sorted.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(pl.items.reserve(items.size()));
@@ -459,6 +483,15 @@ static void boundary_segments(const swimm_hip_ctx *c, const Plan &pl, std::vecto
     if (max_cols) *max_cols = mx;
 }
 
+// Multi-pass query, whole list in one boundary run: the even- and the odd-ranked groups go through their passes as two
+// kernels on two streams.  A pass of one half cannot start before the previous pass of the same half has ended, but
+// it can start while the other half is in full swing, so the end of every launch -- the last workgroups finishing
+// alone, 4 % of a 4 ms pass on a 2e8-residue database -- and the start of the next are covered by the other kernel.
+static bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &pl, size_t n_segs)
+{
+    return c->opt_dynamic && c->opt_split && qp.passes > 1 && n_segs == 1 && pl.n_wg >= 2 && pl.split_n[1] >= (uint32_t)pl.n_wg;
+}
+
 int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row)
 {
     std::vector<std::pair<uint32_t, uint32_t>> segs;
@@ -466,6 +499,34 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
     if (c->opt_dynamic && qp.passes > 1) boundary_segments(c, pl, segs, &seg_cols);
     else segs.push_back({0u, pl.n_items});
     if (qp.passes > 1) HIP_TRY(c->d_bnd.reserve(seg_cols * 64));
+    if (use_split(c, qp, pl, segs.size())) {
+        HIP_TRY(hipEventRecord(c->ev_a, c->stream));               // stream B joins after everything queued so far
+        HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_a, 0));
+        // every kernel asks for the full complement of workgroups: the two kernels of a pass share the CUs while both
+        // have work, and the one that still has groups left takes over the slots the other one frees
+        const int n_half = pl.n_wg;
+        for (int pass = 0; pass < qp.passes; ++pass)
+            for (int h = 0; h < 2; ++h) {
+                PipeParams p{};
+                fill_common(c, qp, p);
+                if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
+                p.items = pl.split_items.p + (h ? pl.split_n[0] : 0);
+                p.n_items = pl.split_n[h];
+                p.max_steps = (uint32_t)std::min<uint64_t>(pl.split_cols[h] / kChunkCols + kMaxWaves + 1, 0x3ffffff0u);
+                p.queue = c->d_queue.p + c->queue_next++;
+                p.r0 = (uint32_t)(pass * qp.W * qp.T);
+                p.first_pass = pass == 0;
+                p.last_pass = pass == qp.passes - 1;
+                p.out = out_row;
+                p.err = c->d_err.p;
+                HIP_TRY(launch_pipe(mode, qp.T, qp.W, (int)std::min<uint32_t>((uint32_t)n_half, pl.split_n[h]), p, h ? c->stream_b : c->stream));
+                c->launches++;
+                c->cells += pl.split_cols[h] * (uint64_t)(qp.W * qp.T) * (mode == Mode::I32 ? 64 : 128);
+            }
+        HIP_TRY(hipEventRecord(c->ev_b, c->stream_b));              // and the main stream continues after both halves
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_b, 0));
+        return 0;
+    }
     for (const auto &sg : segs) {
         uint64_t col0 = 0, seg_chunks = pl.total_chunks;
         if (c->opt_dynamic) {
@@ -660,7 +721,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 }
                 need_bnd = std::max<uint64_t>(need_bnd, cols * 64);
             }
-            launch_total += (size_t)qps[q].passes * nsegs;
+            launch_total += (size_t)qps[q].passes * std::max<size_t>(nsegs, 2);   // two kernels per pass when the list is split over two streams
             tail_cols = std::max<size_t>(tail_cols, dp->tail.cols);
             tail_items = std::max<size_t>(tail_items, dp->tail.n);
             max_passes = std::max(max_passes, (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
@@ -849,7 +910,8 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     swimm_hip_ctx *c = new swimm_hip_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream_b) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -872,6 +934,9 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->ev_tail3) (void)hipEventDestroy(c->ev_tail3);
     for (hipEvent_t e : c->ev_query) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -1213,6 +1278,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         if (value < 1 || value > 1000) return fail("tail_frac must be 1..1000 (percent of a CU's mean load)");
         c->opt_tail_frac = value;
         release_plans(c);
+    } else if (!strcmp(key, "split")) {
+        c->opt_split = value != 0;
     } else if (!strcmp(key, "dynamic")) {
         c->opt_dynamic = value != 0;
     } else if (!strcmp(key, "f16")) {

@@ -489,7 +489,8 @@ static void boundary_segments(const swimm_hip_ctx *c, const Plan &pl, std::vecto
 // alone, 4 % of a 4 ms pass on a 2e8-residue database -- and the start of the next are covered by the other kernel.
 static bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &pl, size_t n_segs)
 {
-    return c->opt_dynamic && c->opt_split && qp.passes > 1 && n_segs == 1 && pl.n_wg >= 2 && pl.split_n[1] >= (uint32_t)pl.n_wg;
+    // (two passes gain nothing: measured -0.3 % on c2)
+    return c->opt_dynamic && c->opt_split && qp.passes > 2 && n_segs == 1 && pl.n_wg >= 2 && pl.split_n[1] >= (uint32_t)pl.n_wg;
 }
 
 int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row)

@@ -659,6 +659,8 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     HIP_TRY(hipSetDevice(c->device));
     if (refresh_plans(c)) return 1;
     const uint32_t qn = qe - qb;
+    const bool dbg = getenv("SWIMM_HIP_DEBUG") != nullptr;
+    const double t_begin = now_s();
     const uint16_t *qm = c->qm.data() + qb;
     const uint32_t *qdisp = c->qdisp.data() + qb;
     const uint64_t S = (uint64_t)c->groups.size() * kGroupSeqs;
@@ -736,6 +738,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         HIP_TRY(c->d_satlist.reserve((size_t)std::min<uint64_t>(S, 0xFFFFFFFEull) + 1));   // every slot could leave a tier's range
         HIP_TRY(c->d_rerun_items.reserve(4096));
     }
+    const double t_sized = now_s();
     HIP_TRY(c->d_err.reserve(1));
     HIP_TRY(hipMemsetAsync(c->d_err.p, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -767,6 +770,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
         HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->stream2));
     }
+    const double t_issued = now_s();
     // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
     // f16 results >= 2048 are re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; each
     // re-run is a lane-systolic item (one wave per alignment), issued on stream 3 as soon as the query's own
@@ -862,6 +866,9 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->kernel_ms += ms;
+    if (dbg)
+        fprintf(stderr, "swimm_hip: queries %u..%u: plans + buffers %.3f s, launches issued %.3f s, ladder + drain %.3f s (device %.3f s)\n", qb, qe,
+                t_sized - t_begin, t_issued - t_sized, now_s() - t_issued, ms * 1e-3);
     uint32_t werr = 0;
     HIP_TRY(hipMemcpy(&werr, c->d_err.p, sizeof werr, hipMemcpyDeviceToHost));
     if (werr) return fail("pipeline watchdog expired (code %u): results discarded", werr);

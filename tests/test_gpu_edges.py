@@ -151,3 +151,42 @@ def test_mass_promotion():
     n = len(seqs)
     assert np.array_equal(got[:, :n], want[:, :n])
     assert (want[0, :n] >= 2048).sum() > 65536 and st["promoted"] >= 40
+
+
+def test_random_small_cases():
+    """120 seeded random searches (database shape, queries, matrix, gaps, launch options) against the exact oracle"""
+    rng = np.random.default_rng(20260104)
+    mats = ["blosum45", "blosum50", "blosum62", "blosum80", "blosum90", "pam30", "pam70", "pam250"]
+    for case in range(120):
+        n_seq = int(rng.integers(1, 400))
+        hi = int(rng.choice([12, 70, 300, 900]))
+        lens = rng.integers(0 if rng.random() < 0.2 else 1, hi + 1, n_seq)
+        seqs = [rnd(rng, int(n)) for n in lens]
+        nq = int(rng.integers(1, 4))
+        qlen_hi = int(rng.choice([8, 40, 200, 700, 1300]))
+        queries = [rnd(rng, int(rng.integers(1, qlen_hi + 1))) for _ in range(nq)]
+        if rng.random() < 0.3 and n_seq > 3:          # plant a close relative so that high scores occur
+            src = queries[-1]
+            seqs[int(rng.integers(0, n_seq))] = np.concatenate([rnd(rng, 5), src, rnd(rng, 3)]).astype(np.int8)
+        go, ge = int(rng.integers(0, 20)), int(rng.integers(0, 6))
+        opts = {}
+        if rng.random() < 0.5:
+            opts["rows_per_wave"] = int(rng.choice([8, 12, 16, 20, 24, 28, 32, 36]))
+        if rng.random() < 0.5:
+            opts["waves"] = int(rng.integers(1, 13))
+        if rng.random() < 0.4:
+            opts["tail_mode"] = int(rng.choice([1, 2]))
+        if rng.random() < 0.2:
+            opts["f16"] = 0
+            opts.pop("rows_per_wave", None) if opts.get("rows_per_wave") not in (16, 24, 32) else None
+        if rng.random() < 0.2:
+            opts["dynamic"] = 0
+        if rng.random() < 0.2:
+            opts["split"] = 0
+        if rng.random() < 0.1:
+            opts = {"force_i32": 1}
+        try:
+            run_case(seqs, queries, matrix=str(rng.choice(mats)), go=go, ge=ge, opts=opts, vl=int(rng.choice([16, 32, 64, 128])),
+                     max_chunk=int(rng.choice([3000, 40000, 1 << 20])))
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: n_seq={n_seq} queries={[len(q) for q in queries]} go={go} ge={ge} opts={opts}") from e

@@ -270,6 +270,11 @@ def main():
             full, _ = searcher.search(chunks.vc * 128)
             ok = bool(np.array_equal(full[0, :shard["n"]][::stride], cpu_scores))
             out["cpu_baseline"]["matches_gpu"] = ok
+            try:
+                model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except Exception:
+                model = "unknown"
+            out["cpu_baseline"]["cpu_model"] = model
             if not ok:
                 raise SystemExit("GPU scores differ from the CPU reference on the benchmark shard")
         print(json.dumps(out), flush=True)

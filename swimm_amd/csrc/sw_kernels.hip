@@ -6,28 +6,28 @@
 // keeping only max H.  Inter-task SIMD: one vector lane owns one database sequence.
 //
 // How it is mapped here (not a translation of the SSE/AVX2/KNC loops):
-//   * one wavefront lane owns TWO database sequences, packed as 2 x int16 in every VGPR
-//     (v_pk_add_i16 clamp / v_pk_max_i16 / v_pk_sub_u16 clamp: the narrowest packed integer
-//     lane CDNA4 has -- there is no packed int8 VALU), so one wave aligns 128 sequences;
-//   * a workgroup is a systolic pipeline of W waves over the QUERY: wave k owns query rows
-//     [k*T, (k+1)*T) in registers (H and E per row), walks the database columns in chunks of
-//     4, and hands the bottom row (H, F per column) to wave k+1 through an LDS ring, one
-//     chunk behind.  Only when the query is longer than W*T rows does a boundary row go
-//     through HBM, once per pass (the "strip" traffic of SURVEY.md 8d with T_eff = W*T);
-//   * the substitution lookup is a query profile staged in LDS, prof[d][row] int16: one
-//     ds_read_b64 fetches the scores of 4 consecutive query rows for a lane's residue d.
-//     The 25 code rows sit 8 bytes (mod 256) apart so the 25 possible addresses of a
-//     32-lane group fall on 25 different bank pairs: no bank conflicts whatever the residues;
-//   * each workgroup processes a host-built list of groups as ONE continuous column stream,
-//     so the pipeline fills and drains once per launch, not once per group;
-//   * saturation (lane best == 32767) is detected afterwards and those half-groups are re-run
-//     by the int32 instantiation of the same kernel (the reference's int8 -> int16 -> int32
-//     ladder, CPUsearch.c:678-957, with int16 as the first rung).
+//   * one wavefront lane owns TWO database sequences, packed 2 x 16 bit in every VGPR, so one wave aligns 128
+//     sequences.  First tier: packed binary16 integers (v_pk_add_f16 / v_pk_maximum3_f16, exact below 2048);
+//     alignments that reach 2048 are re-run as packed int16 (v_pk_add_i16 clamp / v_pk_max_i16 /
+//     v_pk_sub_u16 clamp), those that reach 32767 in int32 -- the reference's int8 -> int16 -> int32 ladder
+//     (CPUsearch.c:678-957) one rung higher: CDNA4 has no packed int8 VALU;
+//   * sw_pipe_kernel: a workgroup is a systolic pipeline of W waves over the QUERY: wave k owns query rows
+//     [k*T, (k+1)*T) in registers (H and E per row), walks the database columns in chunks of 4, and hands the
+//     bottom row (H, F per column) to wave k+1 through an LDS ring, one chunk behind.  Only when the query is
+//     longer than W*T rows does a boundary row go through HBM, once per pass (the "strip" traffic of SURVEY.md 8d
+//     with T_eff = W*T);
+//   * the substitution lookup is a query profile staged in LDS, prof[d][row]: one ds_read_b128 fetches the scores
+//     of 8 consecutive query rows for a lane's residue d; the two sequences' halves are combined by v_perm_b32.
+//     The 25 code rows sit 16 bytes (mod 256) apart, so two residues share LDS banks only if they are equal mod 16;
+//   * workgroups are persistent and align device groups back to back as ONE continuous column stream (the pipeline
+//     fills and drains once per launch); which group comes next is decided by a longest-first queue (first two
+//     rounds dealt, then one global cursor) -- see the kernel;
+//   * sw_lane_kernel: the other axis of parallelism, one wave per alignment with the lanes along the query, for
+//     the few very long sequences and for the promotion re-runs.
 //
-// E and F are kept clamped at >= 0.  That is exact: H already has a 0 floor, so replacing E by
-// max(E, 0) (and F likewise) never changes any H, and max(0, max(E,0) - ge, H - goe) equals
-// max(0, E - ge, H - goe) for ge >= 0.  It buys unsigned-saturating subtracts (no separate
-// max with 0) in the packed path.
+// In the packed-int16 tier E and F are kept clamped at >= 0.  That is exact: H already has a 0 floor, so replacing
+// E by max(E, 0) (and F likewise) never changes any H, and max(0, max(E,0) - ge, H - goe) equals
+// max(0, E - ge, H - goe) for ge >= 0.  It buys unsigned-saturating subtracts (no separate max with 0).
 #include "sw_kernels.h"
 
 namespace swimm {

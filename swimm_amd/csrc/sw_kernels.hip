@@ -611,9 +611,6 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     typedef typename Ops::V V;
     constexpr int TR = kLaneRows, C = kChunkCols, RP = 64 * TR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // these waves carry the critical path (the longest alignments, or the re-runs a query is waiting for) and share
-    // the SIMDs with bulk waves that run at priorities 3..0: keep them at the top
-    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int PS = prof_row_bytes(RP);
     const uint32_t pass = blockIdx.x / p.wg_per_pass;
@@ -634,7 +631,9 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
         }
     }
     __syncthreads();
-    __builtin_amdgcn_s_setprio(2);   // these waves are long serial chains: let them issue ahead of bulk waves on the same SIMD
+    // these waves are long serial chains (the longest alignments, or re-runs a query is waiting for) beside bulk waves
+    // that step through priorities 3..0: stay near the top (priority 0 or 3 measured the same on c3)
+    __builtin_amdgcn_s_setprio(2);
     const unsigned char *my_prof = smem + lane * TR * 2;
     const int last_lane = (int)((rows + TR - 1) / TR) - 1;      // lane holding the query's last rows in this pass
     const V goe = Ops::splat(p.goe), ge = Ops::splat(p.ge);

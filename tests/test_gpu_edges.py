@@ -190,3 +190,12 @@ def test_random_small_cases():
                      max_chunk=int(rng.choice([3000, 40000, 1 << 20])))
         except AssertionError as e:
             raise AssertionError(f"case {case}: n_seq={n_seq} queries={[len(q) for q in queries]} go={go} ge={ge} opts={opts}") from e
+
+
+def test_many_queries():
+    """300 queries in one call (events, cursors and profiles per query), with and without one-query batches"""
+    rng = np.random.default_rng(5)
+    seqs = [rnd(rng, int(n)) for n in rng.integers(1, 260, 700)]
+    queries = [rnd(rng, int(n)) for n in rng.integers(1, 180, 300)]
+    run_case(seqs, queries, opts={"tail_mode": 2})
+    run_case(seqs, queries[:60], opts={"score_mib": 0})

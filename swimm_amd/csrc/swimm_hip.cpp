@@ -165,6 +165,7 @@ struct swimm_hip_ctx {
     DevBuf<uint32_t> d_err;             // pipeline watchdog word
     DevBuf<unsigned long long> d_stamps;   // diagnostic build only
     LaneScratch tail_scratch;           // lane kernel on stream 2 (long-sequence tail)
+    LaneScratch tail_scratch_a, tail_scratch_b;   // one-pass queries that run whole on the main stream / on stream_b
     LaneScratch rerun_scratch;          // lane kernel on stream 3 (promotion re-runs)
     DevBuf<LaneItem> d_rerun_items;
     DevBuf<uint32_t> d_satlist;
@@ -256,7 +257,9 @@ static const float kShapeGcups[8][16] = {
 // `room_for_lane_waves`: the database has a long-sequence tail that the lane kernel aligns on a second stream
 // while this kernel runs; only shapes that leave the 80 VGPRs per SIMD lane a lane-systolic wave needs are
 // admitted (e.g. 3 waves x 144, 4 x 104).
-int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, QueryPlan *out)
+// `overlapped`: the query runs beside two others (one-pass queries in rotation, see search_device), which cover the
+// workgroups that finish early: the makespan term is dropped.
+int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bool overlapped, QueryPlan *out)
 {
     double best_cost = -1;
     for (int ti = 7; ti >= 0; --ti) {
@@ -279,7 +282,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, Qu
             // a launch (pipeline fill and drain, staging, the last workgroups running alone: ~0.15 ms, which is what
             // makes fewer, taller passes the better plan on a database of 1e8 residues)
             const double pass_s = (double)c->total_cols * kGroupSeqs * T * W / ((double)kShapeGcups[ti][W - 1] * 1e9)
-                                  * (passes > 1 && W < 8 ? 1.17 : 1.0) * plan_imbalance(c, c->num_cu * per_cu);
+                                  * (passes > 1 && W < 8 ? 1.17 : 1.0) * (overlapped ? 1.0 : plan_imbalance(c, c->num_cu * per_cu));
             const double cost = passes * (pass_s + 150e-6);
             if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
                 best_cost = cost;
@@ -412,16 +415,17 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, int n_wg)
     return is_tail;
 }
 
-int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, DbPlan **out)
+int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool whole_db, DbPlan **out)
 {
-    const int key = n_wg | (mode == Mode::I32 ? (1 << 30) : 0);   // packed int16 and f16 share plans
+    const int key = n_wg | (mode == Mode::I32 ? (1 << 30) : 0) | (whole_db ? (1 << 29) : 0);   // packed int16 and f16 share plans
     auto it = c->plans.find(key);
     if (it != c->plans.end()) { *out = &it->second; return 0; }
     std::vector<WorkUnit> units;
     std::vector<LaneItem> tail;
     uint64_t bnd_cols = 0;
     if (mode != Mode::I32) {
-        const std::vector<uint8_t> is_tail = pick_tail(c, n_wg);
+        std::vector<uint8_t> is_tail = pick_tail(c, n_wg);
+        if (whole_db) std::fill(is_tail.begin(), is_tail.end(), 0);   // every group through the pipeline kernel
         for (uint32_t g = 0; g < c->groups.size(); ++g) {
             const GroupDesc &gd = c->groups[g];
             if (!is_tail[g]) { units.push_back(WorkUnit{g, 0, 0, gd.ncols, c->group_col_off[g]}); continue; }
@@ -493,7 +497,8 @@ static bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &p
     return c->opt_dynamic && c->opt_split && qp.passes > 2 && n_segs == 1 && pl.n_wg >= 2 && pl.split_n[1] >= (uint32_t)pl.n_wg;
 }
 
-int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row)
+// `st`: stream of the one-kernel-per-pass path (one-pass queries rotate over three streams)
+int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st)
 {
     std::vector<std::pair<uint32_t, uint32_t>> segs;
     uint64_t seg_cols = pl.bnd_cols;
@@ -556,17 +561,17 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
             p.out = out_row;
 #ifdef SWIMM_STAMPS
             HIP_TRY(c->d_stamps.reserve(16 * 8 + 3072));
-            HIP_TRY(hipMemsetAsync(c->d_stamps.p, 0, 16 * 8 * sizeof(unsigned long long), c->stream));
-            HIP_TRY(hipMemsetAsync(c->d_stamps.p + 15 * 8 + 2, 0xff, sizeof(unsigned long long), c->stream));   // min slot
+            HIP_TRY(hipMemsetAsync(c->d_stamps.p, 0, 16 * 8 * sizeof(unsigned long long), st));
+            HIP_TRY(hipMemsetAsync(c->d_stamps.p + 15 * 8 + 2, 0xff, sizeof(unsigned long long), st));   // min slot
             p.stamps = c->d_stamps.p;
 #endif
             p.err = c->d_err.p;
-            HIP_TRY(launch_pipe(mode, qp.T, qp.W, n_wg, p, c->stream));
+            HIP_TRY(launch_pipe(mode, qp.T, qp.W, n_wg, p, st));
 #ifdef SWIMM_STAMPS
             {
                 unsigned long long h[16 * 8];
-                HIP_TRY(hipMemcpyAsync(h, c->d_stamps.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
+                HIP_TRY(hipMemcpyAsync(h, c->d_stamps.p, sizeof h, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
                 for (int w = 0; w < qp.W; ++w)
                     fprintf(stderr, "stamps wave %2d: load/wait %8.0f  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active of %llu steps per wg)\n",
                             w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4],
@@ -678,9 +683,27 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         lane_room = c->opt_tail_mode == 1 || (double)longest > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
     }
     std::vector<QueryPlan> qps(qn);
+    std::vector<uint8_t> rotated(qn, 0);
+    uint32_t n_short = 0;
+    for (uint32_t q = 0; q < qn; ++q) n_short += qm[q] <= 64 * kLaneRows;
+    // (with a handful of short queries the last ones' chains would stick out at the end of the search; and a database
+    // with an extreme sequence -- c3's 35 000 residues are 6x a CU's mean load -- keeps the tail kernel, whose chain
+    // is 3.6x faster per column than a 4-wave workgroup's)
+    uint32_t longest_cols = 0;
+    for (const GroupDesc &g : c->groups) longest_cols = std::max(longest_cols, g.ncols);
+    const bool many_short = n_short >= 8;
+    const bool rotate = many_short && (double)longest_cols <= 2.0 * (double)c->total_cols / c->num_cu;
     size_t prof_elems = 0;
     for (uint32_t q = 0; q < qn; ++q) {
-        if (choose_plan(c, main_mode, qm[q], lane_room, &qps[q])) return 1;
+        // Eight or more short queries in the batch: those that fit one pass run whole -- every group through the
+        // pipeline kernel, no tail kernel -- on three streams in rotation (below); a long sequence's serial chain,
+        // which bounds a lone short query, is then covered by the neighbours' work.
+        rotated[q] = 0;
+        if (rotate && qm[q] <= 64 * kLaneRows) {
+            if (choose_plan(c, main_mode, qm[q], false, true, &qps[q])) return 1;
+            rotated[q] = qps[q].passes == 1;
+        }
+        if (!rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;
         if (getenv("SWIMM_HIP_DEBUG"))
             fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
         const uint32_t lane_rows = (uint32_t)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
@@ -713,7 +736,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             int per_cu = 1;
             if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
             DbPlan *dp = nullptr;
-            if (get_db_plan(c, main_mode, c->num_cu * per_cu, &dp)) return 1;
+            if (get_db_plan(c, main_mode, c->num_cu * per_cu, rotated[q] != 0, &dp)) return 1;
             size_t nsegs = 1;
             if (qps[q].passes > 1 && dp->have_main) {
                 uint64_t cols = dp->main.bnd_cols;
@@ -734,6 +757,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
         if (reserve_lane_scratch(c->tail_scratch, tail_cols, tail_items, max_passes)) return 1;
+        if (reserve_lane_scratch(c->tail_scratch_a, 0, tail_items, 1) || reserve_lane_scratch(c->tail_scratch_b, 0, tail_items, 1)) return 1;
         if (reserve_lane_scratch(c->rerun_scratch, (size_t)1 << 22, 4096, max_passes)) return 1;
         HIP_TRY(c->d_satlist.reserve((size_t)std::min<uint64_t>(S, 0xFFFFFFFEull) + 1));   // every slot could leave a tier's range
         HIP_TRY(c->d_rerun_items.reserve(4096));
@@ -744,6 +768,8 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_ready, 0));
+    uint32_t one_pass_seen = 0;
     HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
     while (c->ev_query.size() < 2 * (size_t)qn) {
         hipEvent_t e;
@@ -757,18 +783,36 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         int per_cu = 1;
         if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
         DbPlan *dp = nullptr;
-        if (get_db_plan(c, main_mode, c->num_cu * per_cu, &dp)) return 1;
+        if (get_db_plan(c, main_mode, c->num_cu * per_cu, rotated[q] != 0, &dp)) return 1;
         int32_t *row = c->d_scores.p + (size_t)q * S;
         if (getenv("SWIMM_HIP_DEBUG"))
             fprintf(stderr, "swimm_hip: query %u: %d workgroups (%d per CU), %u tail items, main %s\n", q, dp->main.n_wg, per_cu, dp->tail.n, dp->have_main ? "yes" : "no");
-        // the long-sequence tail (a few long serial chains, one wave each) runs on its own stream beside the
-        // bulk kernel: 3 bulk waves (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly
-        // (one tail launch at a time: several at once were measured 5 % slower on c3, and the chained passes of
-        // concurrent launches could wait for each other's workgroups)
-        if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, c->stream2, c->tail_scratch)) return 1;
-        if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row)) return 1;
-        HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
-        HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->stream2));
+        // The long-sequence tail (a few long serial chains, one wave each) runs beside the bulk kernel: 3 bulk waves
+        // (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly.  One tail launch at a time: several were
+        // measured 5 % slower on c3, and the chained passes of concurrent launches could wait for each other's workgroups.
+        //
+        // A batch of short one-pass queries is different (see the plans above): each of them is bound from below by
+        // the longest sequence's serial chain (2.4 ms for 5 000 residues, longer than the query's whole bulk work on
+        // a database of 1e8 residues), wherever that sequence is aligned.  They run whole on one of three streams in
+        // rotation, so that three are in flight and each one's chain is covered by the others' work: 300 queries of
+        // 100 residues against 1e8: 3 480 -> 4 750 GCUPS, of 40 residues: 1 570 -> 3 000.  (Three streams, because HIP
+        // multiplexes streams onto four hardware queues and the fourth carries the promotion re-runs; with seven
+        // streams a tail kernel landed in the bulk stream's queue and held it back: -18 % on c3.)
+        hipStream_t tail_stream = c->stream2, bulk_stream = c->stream;
+        LaneScratch *tail_scratch = &c->tail_scratch;
+        // (with an extreme sequence in the database the short queries keep their tail kernel, but still take turns on
+        // the three streams: three 17 ms chains at a time instead of one)
+        if (rotated[q] || (many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows)) {
+            switch (one_pass_seen++ % 3) {
+            case 0: tail_stream = bulk_stream = c->stream; tail_scratch = &c->tail_scratch_a; break;
+            case 1: tail_stream = bulk_stream = c->stream_b; tail_scratch = &c->tail_scratch_b; break;
+            default: tail_stream = bulk_stream = c->stream2; break;
+            }
+        }
+        if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
+        if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row, bulk_stream)) return 1;
+        HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
+        HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
     }
     const double t_issued = now_s();
     // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
@@ -859,6 +903,8 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     }
     HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
+    HIP_TRY(hipEventRecord(c->ev_b, c->stream_b));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_b, 0));
     HIP_TRY(hipEventRecord(c->ev_tail3, c->stream3));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail3, 0));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -937,7 +983,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
     c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
-    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
+    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_a.release(); c->tail_scratch_b.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);

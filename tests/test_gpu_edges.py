@@ -197,5 +197,7 @@ def test_many_queries():
     rng = np.random.default_rng(5)
     seqs = [rnd(rng, int(n)) for n in rng.integers(1, 260, 700)]
     queries = [rnd(rng, int(n)) for n in rng.integers(1, 180, 300)]
-    run_case(seqs, queries, opts={"tail_mode": 2})
+    run_case(seqs, queries, opts={"tail_mode": 2})                  # short queries in rotation over three streams, no tail kernel
     run_case(seqs, queries[:60], opts={"score_mib": 0})
+    run_case(seqs + [rnd(rng, 9000)], queries[:40])                 # an extreme sequence: the rotating queries keep their tail kernel
+    run_case(seqs + [rnd(rng, 700)], queries[100:140] + [rnd(rng, 800)])   # short and multi-pass queries mixed

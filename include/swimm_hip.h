@@ -116,6 +116,7 @@ int swimm_hip_last_plan(swimm_hip_ctx *ctx, uint32_t q, int *rows_per_wave, int 
  *   "tail_mode"      0 = auto: unusually long groups go through the lane-systolic kernel, 1 = every group, 2 = none
  *   "tail_frac"      a group is "unusually long" above this percentage of a CU's mean load (default 50)
  *   "dynamic"        1 = default: workgroups pull groups from a global queue; 0 = static longest-first partition
+ *   "lane_rows"      1 = default: one-pass lane-systolic launches of short queries use 2 / 4 query rows per lane; 0 = always 8
  *   "split"          1 = default: a query of three or more passes runs the even- and odd-ranked groups as two kernels on two streams,
  *                    so that the end of one launch is covered by the other; 0 = one kernel per pass
  *   "score_mib"      HBM budget of the score rows (4 B per query and sequence): the query list is walked in batches

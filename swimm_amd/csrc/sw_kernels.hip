@@ -583,7 +583,7 @@ __device__ __forceinline__ uint32_t dpp_shr1(uint32_t prev, uint32_t lane0_value
 
 constexpr uint32_t kFlagStart = 1u << 16, kFlagEnd = 1u << 17, kFlagReal = 1u << 18;   // kFlagReal: a column of an item (not pipeline fill/drain)
 
-size_t lane_lds_bytes() { return round16((size_t)kCodes * prof_row_bytes(64 * kLaneRows)); }
+size_t lane_lds_bytes(int rows_per_lane) { return round16((size_t)kCodes * prof_row_bytes(64 * rows_per_lane)); }
 
 // what lane 0 feeds into the pipeline for one chunk of 4 columns (wave-uniform)
 struct LaneFeed {
@@ -604,12 +604,24 @@ struct LaneFeed {
 // No deadlock: the grid never exceeds one workgroup per CU (so all of it becomes resident), blocks are
 // pass-major (producers are dispatched first), every pass consumes the items in the same order and pass 0
 // never waits; all spins are bounded and report through p.err.
-template <bool PK>
+// the scores of a lane's TR = 2 NW query rows for one residue: one ds_read_b128 / b64 / b32
+template <int NW>
+__device__ __forceinline__ void lane_prof_load(const unsigned char *q, uint32_t (&w)[NW])
+{
+    if (NW == 4) { const uint4 v = *(const uint4 *)q; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    else if (NW == 2) { const uint2 v = *(const uint2 *)q; w[0] = v.x; w[1] = v.y; }
+    else { w[0] = *(const uint32_t *)q; }
+}
+
+// TR = query rows per lane: 8 (512 rows per pass, chained passes for longer queries); 4 and 2 for queries of up to 256 /
+// 128 rows, whose step -- a serial walk down the lane's rows -- is then that much shorter, and with it the time a
+// 35 000-residue sequence holds up a short query.
+template <bool PK, int TR>
 __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
 {
     typedef typename std::conditional<PK, OpsPK, OpsI32>::type Ops;
     typedef typename Ops::V V;
-    constexpr int TR = kLaneRows, C = kChunkCols, RP = 64 * TR;
+    constexpr int C = kChunkCols, RP = 64 * TR, NW = TR / 2;   // NW dwords of profile per lane and residue
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int PS = prof_row_bytes(RP);
@@ -646,7 +658,7 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     // can issue the profile reads of its next column before it computes the current one.
     uint32_t oDn = 0x1818u;                  // residues this lane will hand to lane+1 (already one step ahead)
     uint32_t Dcur = 0x1818u;                 // residues + flags of the column this lane computes in this step
-    uint4 acur = make_uint4(0, 0, 0, 0), bcur = make_uint4(0, 0, 0, 0);
+    uint32_t acur[NW] = {}, bcur[NW] = {};
     uint32_t oH = 0, oF = 0, oT = 0, oS = 0, oC = 0;
     uint2 pb = make_uint2(0u, 0u);           // boundary-side values of the column lane 0 fed one step ago
     uint32_t pitem = 0, pcol = 0;
@@ -739,9 +751,9 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             if (PK) d0 |= ((cur.wb >> (8 * jj)) & 0xffu) << 8;
             // residue stream, one step ahead: fetch the scores of the NEXT column now
             const uint32_t Dn = dpp_shr1(oDn, d0);
-            const uint4 an = *(const uint4 *)(my_prof + (Dn & 0xffu) * PS);
-            uint4 bn = make_uint4(0, 0, 0, 0);
-            if (PK) bn = *(const uint4 *)(my_prof + ((Dn >> 8) & 0xffu) * PS);
+            uint32_t an[NW], bn[NW] = {};
+            lane_prof_load<NW>(my_prof + (Dn & 0xffu) * PS, an);
+            if (PK) lane_prof_load<NW>(my_prof + ((Dn >> 8) & 0xffu) * PS, bn);
             // boundary stream: every lane takes its left neighbour's bottom row, lane 0 the stored top boundary
             const uint32_t Hin = dpp_shr1(oH, pb.x), Fin = dpp_shr1(oF, pb.y);
             const uint32_t Tin = dpp_shr1(oT, 0u), Sin = dpp_shr1(oS, pitem), Cin = dpp_shr1(oC, pcol);
@@ -754,17 +766,17 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             V hd = diag;
             diag = Ops::from_bits(Hin);
             V F = Ops::from_bits(Fin);
-            const uint32_t aw[4] = {acur.x, acur.y, acur.z, acur.w};
+            const uint32_t *aw = acur;
             if (PK) {
-                const uint32_t bw[4] = {bcur.x, bcur.y, bcur.z, bcur.w};
+                const uint32_t *bw = bcur;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < NW; ++q) {
                     cell<Ops>(hd, H[2 * q], E[2 * q], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)), goe, ge);
                     cell<Ops>(hd, H[2 * q + 1], E[2 * q + 1], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < NW; ++q) {
                     cell<Ops>(hd, H[2 * q], E[2 * q], F, best, Ops::from_bits((uint32_t)(int)(short)(aw[q] & 0xffffu)), goe, ge);
                     cell<Ops>(hd, H[2 * q + 1], E[2 * q + 1], F, best, Ops::from_bits((uint32_t)((int)aw[q] >> 16)), goe, ge);
                 }
@@ -785,7 +797,9 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
                 }
             }
             // advance both streams
-            oDn = Dn; Dcur = Dn; acur = an; bcur = bn;
+            oDn = Dn; Dcur = Dn;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) { acur[q] = an[q]; bcur[q] = bn[q]; }
             pb = cur.b[jj]; pitem = cur.item; pcol = cur.col0 + jj;
         }
         if (!last_pass && ((hist_real >> 16) & 1u)) {
@@ -806,13 +820,23 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     }
 }
 
-hipError_t launch_lane(Mode mode, int n_wg, const LaneParams &p, hipStream_t s)
+template <int TR>
+static hipError_t launch_lane_tr(Mode mode, int n_wg, const LaneParams &p, hipStream_t s)
+{
+    const size_t lds = lane_lds_bytes(TR);
+    if (mode == Mode::PK16) hipLaunchKernelGGL((sw_lane_kernel<true, TR>), dim3(n_wg), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((sw_lane_kernel<false, TR>), dim3(n_wg), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_lane(Mode mode, int rows_per_lane, int n_wg, const LaneParams &p, hipStream_t s)
 {
     if (n_wg < 1) return hipErrorInvalidValue;
-    const size_t lds = lane_lds_bytes();
-    if (mode == Mode::PK16) hipLaunchKernelGGL((sw_lane_kernel<true>), dim3(n_wg), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((sw_lane_kernel<false>), dim3(n_wg), dim3(256), lds, s, p);
-    return hipGetLastError();
+    if (rows_per_lane == 8) return launch_lane_tr<8>(mode, n_wg, p, s);
+    if (p.passes != 1) return hipErrorInvalidValue;          // the short-lane variants are for one-pass queries
+    if (rows_per_lane == 4) return launch_lane_tr<4>(mode, n_wg, p, s);
+    if (rows_per_lane == 2) return launch_lane_tr<2>(mode, n_wg, p, s);
+    return hipErrorInvalidValue;
 }
 
 // ---- re-tile: reference chunk layout -> device groups --------------------------------------

@@ -132,6 +132,7 @@ struct swimm_hip_ctx {
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
     int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
     int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
+    int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
     int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
     int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
     int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
@@ -628,7 +629,9 @@ int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, con
     p.err = c->d_err.p;
     HIP_TRY(hipMemsetAsync(sc.queue.p, 0, passes * sizeof(uint32_t), st));
     if (passes > 1) HIP_TRY(hipMemsetAsync(sc.prog.p, 0, need_prog * sizeof(uint32_t), st));
-    HIP_TRY(launch_lane(mode, passes * per_pass, p, st));
+    // a one-pass launch of a short query uses fewer rows per lane: the serial walk down a lane's rows is the step latency
+    const int rows_per_lane = (passes == 1 && m <= 128 && c->opt_lane_rows) ? 2 : (passes == 1 && m <= 256 && c->opt_lane_rows) ? 4 : kLaneRows;
+    HIP_TRY(launch_lane(mode, rows_per_lane, passes * per_pass, p, st));
     c->launches++;
     c->cells += ll.cell_cols * (uint64_t)rows_pass * passes * (mode == Mode::PK16 ? 2 : 1);
     return 0;
@@ -1332,6 +1335,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         if (value < 1 || value > 1000) return fail("tail_frac must be 1..1000 (percent of a CU's mean load)");
         c->opt_tail_frac = value;
         release_plans(c);
+    } else if (!strcmp(key, "lane_rows")) {
+        c->opt_lane_rows = value != 0;
     } else if (!strcmp(key, "split")) {
         c->opt_split = value != 0;
     } else if (!strcmp(key, "dynamic")) {

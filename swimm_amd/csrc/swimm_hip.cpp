@@ -273,6 +273,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
         for (int W = 1; W <= maxW; ++W) {
             if (c->opt_W > 0 && W != std::min(c->opt_W, maxW)) continue;
             const int passes = (strips + W - 1) / W;
+            if (overlapped && passes != 1) continue;   // only one-pass queries take part in the rotation
             int per_cu = 1;
             if (wgs_per_cu(c, mode, T, W, &per_cu)) return 1;
             if (room_for_lane_waves && !c->opt_T) {
@@ -703,8 +704,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         // which bounds a lone short query, is then covered by the neighbours' work.
         rotated[q] = 0;
         if (rotate && qm[q] <= 64 * kLaneRows) {
-            if (choose_plan(c, main_mode, qm[q], false, true, &qps[q])) return 1;
-            rotated[q] = qps[q].passes == 1;
+            rotated[q] = choose_plan(c, main_mode, qm[q], false, true, &qps[q]) == 0;   // fails when no one-pass shape exists
         }
         if (!rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;
         if (getenv("SWIMM_HIP_DEBUG"))

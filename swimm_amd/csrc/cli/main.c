@@ -161,7 +161,7 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
 /* Mode 2 (the reference's het_search_*, HETsearch.c:57,96-104: host and devices pull chunks from one queue): here
  * the split is fixed before the search, because the GPUs keep their share resident and search it in one go.  The
  * host's rate is measured on a sample of the shortest sequences, the GPUs' is taken as SWIMM_HYBRID_GPU_GCUPS (default
- * 6500 per device, plus start-up and upload time); the host gets the shortest sequences it can finish in the time
+ * 7500 per device, plus start-up and upload time); the host gets the shortest sequences it can finish in the time
  * the GPUs need for the rest.  Returns the number of sequences for the host (0: not worth it). */
 static uint64_t hybrid_split(const swimm_options *o, const swimm_queries *q, const char *submat, const swimm_db *db, int G)
 {
@@ -189,7 +189,7 @@ static uint64_t hybrid_split(const swimm_options *o, const swimm_queries *q, con
     for (uint64_t i = 0; i < sample; ++i) sample_res += db->lengths[i];
     const double host_rate = (double)sample_res * q->m[0] / (st.seconds > 1e-6 ? st.seconds : 1e-6);   /* cells per second */
     const char *env = getenv("SWIMM_HYBRID_GPU_GCUPS");
-    const double gpu_rate = (env && atof(env) > 0 ? atof(env) : 6500.0) * 1e9 * G;
+    const double gpu_rate = (env && atof(env) > 0 ? atof(env) : 7500.0) * 1e9 * G;
     const double fixed = 0.10 + (double)db->residues / G / 15e9;   /* context creation + pageable upload, measured 0.03 s + 17 GB/s */
     const double Qrows = (double)q->Q;
     /* host_cells / host_rate = fixed + (total - host_cells) / gpu_rate */

@@ -15,12 +15,15 @@ L = np.sort(synth.config_lengths("c2", 0.17)).astype(np.uint16)
 total = int(L.astype(np.int64).sum())
 codes = host.recode(synth.residues(2, 7, 0, total))
 rng = np.random.default_rng(1)
-for (nq, lo, hi) in ((300, 80, 120), (100, 280, 320), (1000, 20, 60), (3, 80, 120), (1, 80, 120)):
+SETS = ((100, 600, 700), (60, 1200, 1400), (200, 50, 1500)) if os.environ.get('SQ_MEDIUM') else ((300, 80, 120), (100, 280, 320), (1000, 20, 60), (100, 600, 700), (60, 1200, 1400), (200, 50, 1500), (3, 80, 120), (1, 80, 120))
+for (nq, lo, hi) in SETS:
     ms = np.sort(rng.integers(lo, hi, nq)).astype(np.uint16)
     a = host.recode(synth.residues(2, 11, 0, int(ms.sum())))
     disp = np.concatenate([[0], np.cumsum(ms.astype(np.int64))]).astype(np.uint32)
     with hip_backend.HipSearcher(0) as s:
         s.add_sequences(L, codes, 0)
+        if os.environ.get('SQ_TAIL_FRAC'):
+            s.set_option('tail_frac', int(os.environ['SQ_TAIL_FRAC']))
         s.set_queries(a, ms, disp, submat.table("blosum62"), 10, 2)
         s.search_topr(10, len(L))
         ts, ti, wt = s.search_topr(10, len(L))

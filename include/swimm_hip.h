@@ -28,6 +28,7 @@
 #ifndef SWIMM_HIP_H_INCLUDED
 #define SWIMM_HIP_H_INCLUDED
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -105,11 +106,16 @@ int swimm_hip_last_stats(swimm_hip_ctx *ctx, double *kernel_ms, uint64_t *cells,
  * rows of the query held per wavefront, wavefronts per workgroup, passes over the database. */
 int swimm_hip_last_plan(swimm_hip_ctx *ctx, uint32_t q, int *rows_per_wave, int *waves, int *passes);
 
+/* Name of the dominant DP kernel of that plan, as the code object carries it and rocprofv3 lists it (demangled, e.g.
+ * "void swimm::sw_pipe_kernel<24, 2, true>(swimm::PipeParams)"), so that a profile can be matched to a search
+ * without guessing.  Measurement aid only (row (d) of SURVEY.md section 8); no reference counterpart. */
+int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t buf_len);
+
 /* Tuning knobs (optional).  key:
  *   "rows_per_wave"  0 = launch shape chosen per query (default); 8, 12, ... 36 forces the rows per wavefront
  *                    (the int16 / int32 first tiers have 16, 24, 32 only)
  *   "waves"          0 = chosen per query; 1..16 forces the wavefronts per workgroup;  "max_waves" caps them
- *   "wgs_per_cu"     0 = by occupancy
+ *   "wgs_per_cu"     0 = by occupancy;  "wg_limit" caps the persistent workgroups of a launch (0 = what the chip holds)
  *   "f16"            1 = default: packed binary16 first tier, exact below 2048, int16 and int32 re-runs above;
  *                    0 = packed int16 first tier
  *   "force_i32"      1 = everything in int32 (one sequence per lane)
@@ -119,11 +125,14 @@ int swimm_hip_last_plan(swimm_hip_ctx *ctx, uint32_t q, int *rows_per_wave, int 
  *   "lane_rows"      1 = default: one-pass lane-systolic launches of short queries use 2 / 4 query rows per lane; 0 = always 8
  *   "split"          1 = default: a query of three or more passes runs the even- and odd-ranked groups as two kernels on two streams,
  *                    so that the end of one launch is covered by the other; 0 = one kernel per pass
+ *   "lane_acquire"   0 = default: chained lane-systolic passes read their predecessor's boundary rows with sc1 loads behind a
+ *                    relaxed poll; 1 = an agent-scope acquire after every poll as well (A/B option)
  *   "score_mib"      HBM budget of the score rows (4 B per query and sequence): the query list is walked in batches
  *                    that fit (default 32768; 0 = one query per batch)
  *   "bnd_mib"        HBM budget of the pass-boundary buffer of multi-pass queries (4x the tiled residue bytes of the
  *                    groups in flight): the group list is cut into runs that fit (default 16384)
- * Unknown key -> error. */
+ * Unknown key -> error.  The environment variable SWIMM_HIP_OPTIONS="key=value,key=value" applies the same knobs to
+ * every context at creation (for swimm_hip_search_chunks and the `swimm` program, whose contexts the caller never sees). */
 int swimm_hip_set_option(swimm_hip_ctx *ctx, const char *key, int value);
 
 /* Whole-call drop-in with the argument list of mic_search_knc_ap_multiple_chunks

@@ -124,9 +124,11 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
     char (*gerr)[512] = calloc((size_t)G, 512);
     double *g_kms = (double *)calloc((size_t)G, sizeof(double));
     uint64_t *g_prom = (uint64_t *)calloc((size_t)G, sizeof(uint64_t));
-#pragma omp parallel num_threads(G)
-    {
-        const int g = omp_get_thread_num();
+    int *g_done = (int *)calloc((size_t)G, sizeof(int));
+    /* one iteration per device (one host thread each when the runtime grants them, MICsearch.c:53; fewer threads only
+     * serialise devices, they cannot drop one) */
+#pragma omp parallel for num_threads(G) schedule(static, 1)
+    for (int g = 0; g < G; ++g) {
         swimm_hip_ctx *ctx = NULL;
         int mine = 0;
         for (uint32_t c = 0; c < n_slabs; ++c) mine += slabs[c].owner == g;
@@ -151,8 +153,11 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
             for (size_t i = 0; i < q->count * top; ++i) if (pi[i] >= 0) pi[i] += (int64_t)first;
         }
         if (ctx) api->destroy(ctx);
+        g_done[g] = 1;
     }
     for (int g = 0; g < G; ++g) if (gerr[g][0]) { printf("SWIMM: GPU %d: %s\n", g, gerr[g]); exit(5); }
+    for (int g = 0; g < G; ++g) if (!g_done[g]) { printf("SWIMM: GPU %d: its share of the database was not searched.\n", g); exit(5); }
+    free(g_done);
     for (int g = 0; g < G; ++g) { if (g_kms[g] > st->kernel_ms) st->kernel_ms = g_kms[g]; st->promoted += g_prom[g]; }
     free(gerr); free(g_kms); free(g_prom); free(slabs);
     st->seconds = swimm_wtime() - tick;

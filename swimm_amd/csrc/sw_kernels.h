@@ -79,6 +79,7 @@ struct LaneParams {
     int32_t *out;
     int goe, ge;
     uint32_t *err;              // watchdog word
+    int agent_acquire;          // 1: consumers of chained passes issue an agent-scope acquire after every poll (A/B option)
 };
 size_t lane_lds_bytes(int rows_per_lane);
 // rows_per_lane: kLaneRows (any query), or 4 / 2 for a one-pass launch of a query of <= 256 / <= 128 rows
@@ -89,6 +90,8 @@ size_t pipe_lds_bytes(int rows_per_wave, int waves);
 bool pipe_has_variant(Mode mode, int rows_per_wave);
 // registers / occupancy of one instantiation (for the host-side launch plan)
 hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, int *num_regs);
+// mangled symbol of the instantiation (nullptr when there is none)
+const char *pipe_kernel_symbol(Mode mode, int rows_per_wave, bool dynamic);
 hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, int n_wg, const PipeParams &p, hipStream_t s);
 
 // Re-tile one reference-layout chunk (sequences.c:506-526 byte interleave) into device groups.

@@ -541,28 +541,42 @@ hipError_t launch_pipe(Mode mode, int T, int W, int n_wg, const PipeParams &p, h
     return hipErrorInvalidValue;
 }
 
-template <int T>
+template <int T, bool DYN>
 static const void *kernel_ptr(Mode mode)
 {
-    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0, true>;
-    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1, true>;
-    return (const void *)sw_pipe_kernel<T, 2, true>;
+    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0, DYN>;
+    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1, DYN>;
+    return (const void *)sw_pipe_kernel<T, 2, DYN>;
+}
+
+template <bool DYN>
+static const void *kernel_ptr_t(Mode mode, int T)
+{
+    if (!pipe_has_variant(mode, T)) return nullptr;
+    if (T == 32) return kernel_ptr<32, DYN>(mode);
+    if (T == 24) return kernel_ptr<24, DYN>(mode);
+    if (T == 16) return kernel_ptr<16, DYN>(mode);
+#define X(t) if (T == t) return (const void *)sw_pipe_kernel<t, 2, DYN>;
+    SWIMM_EXTRA_T(X)
+#undef X
+    return nullptr;
 }
 
 hipError_t pipe_kernel_attributes(Mode mode, int T, int *num_regs)
 {
     hipFuncAttributes a;
-    const void *f = nullptr;
-    if (!pipe_has_variant(mode, T)) return hipErrorInvalidValue;
-    if (T == 32) f = kernel_ptr<32>(mode);
-    else if (T == 24) f = kernel_ptr<24>(mode);
-    else if (T == 16) f = kernel_ptr<16>(mode);
-#define X(t) else if (T == t) f = (const void *)sw_pipe_kernel<t, 2, true>;
-    SWIMM_EXTRA_T(X)
-#undef X
+    const void *f = kernel_ptr_t<true>(mode, T);
+    if (!f) return hipErrorInvalidValue;
     hipError_t e = hipFuncGetAttributes(&a, f);
     if (e == hipSuccess) *num_regs = a.numRegs;
     return e;
+}
+
+// the code object's own (mangled) name of the instantiation a launch plan uses: what rocprofv3 lists, demangled
+const char *pipe_kernel_symbol(Mode mode, int T, bool dynamic)
+{
+    const void *f = dynamic ? kernel_ptr_t<true>(mode, T) : kernel_ptr_t<false>(mode, T);
+    return f ? hipKernelNameRefByPtr(f, nullptr) : nullptr;
 }
 
 // ---- lane-systolic kernel ------------------------------------------------------------------------
@@ -596,11 +610,12 @@ struct LaneFeed {
 
 // Passes of a long query (512 rows each) are CHAINED inside one launch: the workgroups of pass p take the
 // items in the same order as those of pass p-1 and follow them through global memory.  The wave that runs
-// (item, p) publishes, per column, the bottom row of its last lane into bnd[p & 1] with agent-scope stores
-// and, two chunks later (s_waitcnt vmcnt(8): the youngest 8 operations are at least the last two chunks'
-// four stores each, so everything before them has completed), a per-item progress counter; the wave that runs (item, p+1) polls
-// that counter before it feeds the columns to its lane 0.  A 5 478-row query against a 35 000-residue
-// sequence is then 11 waves a few hundred columns apart instead of 11 launches one after the other.
+// (item, p) publishes, per column, the bottom row of its last lane into bnd[p & 1] with write-through agent-scope
+// stores and, one chunk later and behind a full drain of its vector-memory counter, a per-item progress counter (form
+// R1 of the guide's inter-workgroup hand-off: sc1 payload, s_waitcnt vmcnt(0), then the flag); the wave that runs
+// (item, p+1) polls that counter and reads the rows with sc1 loads before it feeds the columns to its lane 0.  A
+// 5 478-row query against a 35 000-residue sequence is then 11 waves a few hundred columns apart instead of 11
+// launches one after the other.
 // No deadlock: the grid never exceeds one workgroup per CU (so all of it becomes resident), blocks are
 // pass-major (producers are dispatched first), every pass consumes the items in the same order and pass 0
 // never waits; all spins are bounded and report through p.err.
@@ -662,8 +677,6 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     uint32_t oH = 0, oF = 0, oT = 0, oS = 0, oC = 0;
     uint2 pb = make_uint2(0u, 0u);           // boundary-side values of the column lane 0 fed one step ago
     uint32_t pitem = 0, pcol = 0;
-    // progress publication (meaningful in the last lane): last real column of the previous chunk / the one before
-
     // producer state (wave-uniform): next chunk to feed
     bool feeding = true, dead = false;
     uint32_t cc = 0, nch = 0, it_lane = 0, it_half = 0, it_bnd = 0, it_idx = 0, seen = 0;
@@ -705,6 +718,13 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
                         __builtin_amdgcn_s_sleep(16);
                     }
                     if (dead) { if (lane == 0) atomicOr(p.err, 4u); feeding = false; return false; }
+                    // The boundary values below are read with agent-scope atomic loads (sc1: they bypass this CU's L1
+                    // and are served by memory the producer's sc1 stores went through to), so nothing stale can be
+                    // hit and the fence only has to keep the compiler from moving those loads above the poll.
+                    // p.agent_acquire = 1 makes it a full agent-scope acquire (buffer_inv sc1) instead: the
+                    // by-the-book form, measured at no gain in safety and a CU-wide L1 invalidate per poll.
+                    if (p.agent_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
 #pragma unroll
                 for (int jj = 0; jj < C; ++jj) {
@@ -725,7 +745,20 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
 
     // wave-uniform history of the chunks fed (bit i = the chunk fed i iterations ago): lane 63 computes, chunk
     // aligned, the chunk that was fed 16 iterations earlier
-    uint32_t hist_real = 0, hist_first = 0, hist_end = 0;
+    uint32_t hist_real = 0;
+    // Publication of the boundary rows to the next pass (cdna_hip_programming.md section 6, Guideline 16, form R1): the
+    // payload is stored write-through (8-byte agent-scope atomic stores = global_store_dwordx2 sc1), the storing wave
+    // drains its vector-memory counter completely -- s_waitcnt vmcnt(0), no reliance on the order in which loads and
+    // stores retire -- and only then stores the progress word (agent-scope atomic store).  The drain sits at the top
+    // of the next chunk, where the wave has to wait for its feed loads anyway, so a chunk's columns become visible one
+    // chunk late and the wait is never for a store that was just issued.
+    bool pub_pending = false;
+    uint32_t pub_item = 0, pub_cols = 0;           // meaningful in lane 63
+    auto publish = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (pub_pending && lane == 63) __hip_atomic_store(prog_out + pub_item, pub_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pub_pending = false;
+    };
     LaneFeed nxt;
     bool more = produce(nxt);
     while (more) {
@@ -740,11 +773,10 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
         }
         cur.item = __builtin_amdgcn_readfirstlane(nxt.item); cur.col0 = __builtin_amdgcn_readfirstlane(nxt.col0);
         cur.half = __builtin_amdgcn_readfirstlane(nxt.half);
+        if (!last_pass) publish();   // the previous chunk's boundary stores have retired (the feed loads were waited for just above)
         more = produce(nxt);         // loads of the next chunk are in flight while this one is computed
         if (!PK && cur.half) cur.wa = cur.wb;
         hist_real = (hist_real << 1) | ((cur.flags[0] & kFlagReal) ? 1u : 0u);
-        hist_first = (hist_first << 1) | ((cur.flags[0] & kFlagStart) ? 1u : 0u);
-        hist_end = (hist_end << 1) | ((cur.flags[C - 1] & kFlagEnd) ? 1u : 0u);
 #pragma unroll
         for (int jj = 0; jj < C; ++jj) {
             uint32_t d0 = ((cur.wa >> (8 * jj)) & 0xffu) | cur.flags[jj];
@@ -803,21 +835,12 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             pb = cur.b[jj]; pitem = cur.item; pcol = cur.col0 + jj;
         }
         if (!last_pass && ((hist_real >> 16) & 1u)) {
-            // Lane 63 has just stored the boundary of the chunk fed 16 iterations ago, which ends at column oC.
-            // Vector-memory operations complete in issue order; the youngest 8 are at least this chunk's and the
-            // previous chunk's 4 stores, so after vmcnt(8) the chunk two back (ending at oC - 8, same item unless
-            // this is the item's first or second chunk) is in memory and may be published.  An item's last chunk is
-            // published at once behind a full wait.
-            if ((hist_end >> 16) & 1u) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 63) __hip_atomic_store(prog_out + oS, oC + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                if (lane == 63 && !((hist_first >> 16) & 3u))
-                    __hip_atomic_store(prog_out + oS, oC + 1 - 2 * C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            // Lane 63 has just stored the boundary of the chunk fed 16 iterations ago, which ends at column oC of item
+            // oS; it is published behind the drain at the top of the next chunk (or after the loop).
+            pub_pending = true; pub_item = oS; pub_cols = oC + 1;
         }
     }
+    if (!last_pass) publish();
 }
 
 template <int TR>

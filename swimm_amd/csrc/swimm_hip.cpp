@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cxxabi.h>
 #include <map>
 #include <queue>
 #include <string>
@@ -109,7 +110,7 @@ struct ChunkRec {
     uint32_t group0 = 0, n_groups = 0;
 };
 
-struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; };
+struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true; };
 
 }  // namespace
 
@@ -136,6 +137,8 @@ struct swimm_hip_ctx {
     int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
     int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
     int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
+    int opt_lane_acquire = 0;           // 1: chained lane passes take an agent-scope acquire after every progress poll (default: sc1 loads only)
+    int opt_wg_limit = 0;               // > 0: at most this many persistent workgroups per pipeline launch (tests: long per-workgroup item sequences on a small database)
     // caches that depend on the resident database / the code objects
     std::map<int, double> imbalance_cache;   // n_wg -> LPT makespan / mean load of the resident database (bulk groups)
     int regs_cache[3][40] = {};         // VGPRs of sw_pipe_kernel<T, tier>, looked up once
@@ -207,6 +210,13 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
 }
 
 std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, int n_wg);
+
+// persistent workgroups of a pipeline launch: what the chip holds, unless the caller caps it
+int n_workgroups(const swimm_hip_ctx *c, int per_cu)
+{
+    const int n = c->num_cu * per_cu;
+    return c->opt_wg_limit > 0 ? std::min(n, c->opt_wg_limit) : n;
+}
 
 // How evenly the bulk groups of the resident database spread over n_wg workgroups: makespan of the longest-first
 // greedy schedule (what the dynamic queue, and the static partition, produce) over the mean load.  1.00x for a
@@ -284,7 +294,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
             // a launch (pipeline fill and drain, staging, the last workgroups running alone: ~0.15 ms, which is what
             // makes fewer, taller passes the better plan on a database of 1e8 residues)
             const double pass_s = (double)c->total_cols * kGroupSeqs * T * W / ((double)kShapeGcups[ti][W - 1] * 1e9)
-                                  * (passes > 1 && W < 8 ? 1.17 : 1.0) * (overlapped ? 1.0 : plan_imbalance(c, c->num_cu * per_cu));
+                                  * (passes > 1 && W < 8 ? 1.17 : 1.0) * (overlapped ? 1.0 : plan_imbalance(c, n_workgroups(c, per_cu)));
             const double cost = passes * (pass_s + 150e-6);
             if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
                 best_cost = cost;
@@ -628,6 +638,7 @@ int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, con
     p.goe = c->open_gap + c->extend_gap;
     p.ge = c->extend_gap;
     p.err = c->d_err.p;
+    p.agent_acquire = c->opt_lane_acquire;
     HIP_TRY(hipMemsetAsync(sc.queue.p, 0, passes * sizeof(uint32_t), st));
     if (passes > 1) HIP_TRY(hipMemsetAsync(sc.prog.p, 0, need_prog * sizeof(uint32_t), st));
     // a one-pass launch of a short query uses fewer rows per lane: the serial walk down a lane's rows is the step latency
@@ -723,7 +734,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         }
     }
     c->last_plans.resize(c->qm.size());
-    for (uint32_t q = 0; q < qn; ++q) c->last_plans[qb + q] = qps[q];
+    for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; c->last_plans[qb + q] = qps[q]; }
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
@@ -739,7 +750,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             int per_cu = 1;
             if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
             DbPlan *dp = nullptr;
-            if (get_db_plan(c, main_mode, c->num_cu * per_cu, rotated[q] != 0, &dp)) return 1;
+            if (get_db_plan(c, main_mode, n_workgroups(c, per_cu), rotated[q] != 0, &dp)) return 1;
             size_t nsegs = 1;
             if (qps[q].passes > 1 && dp->have_main) {
                 uint64_t cols = dp->main.bnd_cols;
@@ -786,7 +797,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         int per_cu = 1;
         if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
         DbPlan *dp = nullptr;
-        if (get_db_plan(c, main_mode, c->num_cu * per_cu, rotated[q] != 0, &dp)) return 1;
+        if (get_db_plan(c, main_mode, n_workgroups(c, per_cu), rotated[q] != 0, &dp)) return 1;
         int32_t *row = c->d_scores.p + (size_t)q * S;
         if (getenv("SWIMM_HIP_DEBUG"))
             fprintf(stderr, "swimm_hip: query %u: %d workgroups (%d per CU), %u tail items, main %s\n", q, dp->main.n_wg, per_cu, dp->tail.n, dp->have_main ? "yes" : "no");
@@ -975,6 +986,25 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
         hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return fail("swimm_hip_create: stream/event creation failed");
+    }
+    // SWIMM_HIP_OPTIONS="key=value,key=value": the same knobs as swimm_hip_set_option, for callers that never see the
+    // context (swimm_hip_search_chunks, the `swimm` program)
+    if (const char *env = getenv("SWIMM_HIP_OPTIONS")) {
+        std::string all(env);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string kv = all.substr(pos, end - pos);
+            pos = end + 1;
+            if (kv.empty()) continue;
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos || eq == 0 || eq + 1 >= kv.size()) { swimm_hip_destroy(c); return fail("SWIMM_HIP_OPTIONS: '%s' is not key=value", kv.c_str()); }
+            char *rest = nullptr;
+            const long v = strtol(kv.c_str() + eq + 1, &rest, 10);
+            if (*rest != 0) { swimm_hip_destroy(c); return fail("SWIMM_HIP_OPTIONS: value of '%s' is not an integer", kv.c_str()); }
+            if (swimm_hip_set_option(c, kv.substr(0, eq).c_str(), (int)v)) { const std::string msg = g_err; swimm_hip_destroy(c); return fail("SWIMM_HIP_OPTIONS: %s", msg.c_str()); }
+        }
     }
     *out = c;
     return 0;
@@ -1227,7 +1257,11 @@ int swimm_hip_search_topr(swimm_hip_ctx *c, uint32_t r, uint64_t n_valid, int32_
         if (search_device(c, qb, qe, &S)) return 1;
         int32_t *out_s = top_scores + (size_t)qb * r;
         int64_t *out_i = top_index + (size_t)qb * r;
-        if (r <= 64) {
+        // the device keys carry the global index in 32 bits (score << 32 | index, + 1): a database part whose indices do not
+        // fit takes the host selection below instead
+        uint64_t max_index = 0;
+        for (const ChunkRec &ch : c->chunks) max_index = std::max<uint64_t>(max_index, ch.first_seq + ch.n_seq + kGroupSeqs);
+        if (r <= 64 && max_index < 0xFFFFFFFEull) {
             // device path: per-block top-64 candidate keys, final selection over n_blocks*64 keys on the host
             std::vector<int64_t> gbase(c->groups.size());
             std::vector<uint32_t> gvalid(c->groups.size());
@@ -1311,6 +1345,20 @@ int swimm_hip_last_plan(swimm_hip_ctx *c, uint32_t q, int *rows_per_wave, int *w
     return 0;
 }
 
+int swimm_hip_last_kernel_name(swimm_hip_ctx *c, uint32_t q, char *buf, size_t buf_len)
+{
+    if (!c || !buf || buf_len == 0) return fail("swimm_hip_last_kernel_name: NULL argument");
+    if (q >= c->last_plans.size()) return fail("swimm_hip_last_kernel_name: query %u was not part of the last search", q);
+    const QueryPlan &qp = c->last_plans[q];
+    const char *sym = pipe_kernel_symbol(qp.mode, qp.T, qp.dynamic);
+    if (!sym) return fail("swimm_hip_last_kernel_name: no kernel for rows_per_wave=%d", qp.T);
+    int status = 0;
+    char *dem = abi::__cxa_demangle(sym, nullptr, nullptr, &status);
+    snprintf(buf, buf_len, "%s", status == 0 && dem ? dem : sym);
+    free(dem);
+    return 0;
+}
+
 int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail("swimm_hip_set_option: NULL argument");
@@ -1346,6 +1394,12 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "tail_mode")) {
         if (value < 0 || value > 2) return fail("tail_mode must be 0 (auto), 1 (all groups via the lane kernel) or 2 (none)");
         c->opt_tail_mode = value;
+        release_plans(c);
+    } else if (!strcmp(key, "lane_acquire")) {
+        c->opt_lane_acquire = value != 0;
+    } else if (!strcmp(key, "wg_limit")) {
+        if (value < 0) return fail("wg_limit must be >= 0 (0 = as many workgroups as the chip holds)");
+        c->opt_wg_limit = value;
         release_plans(c);
     } else if (!strcmp(key, "wgs_per_cu")) {
         if (value < 0 || value > 16) return fail("wgs_per_cu must be 0..16");

@@ -22,7 +22,8 @@ LIB_PATH = os.environ.get("SWIMM_HIP_LIB") or os.path.join(_HERE, "lib", "libswi
 ABI_SYMBOLS = (
     "swimm_hip_abi_version", "swimm_hip_last_error", "swimm_hip_device_count", "swimm_hip_create",
     "swimm_hip_destroy", "swimm_hip_set_queries", "swimm_hip_add_chunk", "swimm_hip_add_sequences", "swimm_hip_clear_db",
-    "swimm_hip_search", "swimm_hip_search_topr", "swimm_hip_last_stats", "swimm_hip_last_plan", "swimm_hip_set_option",
+    "swimm_hip_search", "swimm_hip_search_topr", "swimm_hip_last_stats", "swimm_hip_last_plan", "swimm_hip_last_kernel_name",
+    "swimm_hip_set_option",
     "swimm_hip_search_chunks",
 )
 
@@ -152,6 +153,11 @@ class HipSearcher:
         t = C.c_int(); w = C.c_int(); p = C.c_int()
         _check(self._L.swimm_hip_last_plan(self._ctx, C.c_uint32(q), C.byref(t), C.byref(w), C.byref(p)))
         return {"rows_per_wave": t.value, "waves": w.value, "passes": p.value}
+
+    def last_kernel_name(self, q: int = 0) -> str:
+        buf = C.create_string_buffer(256)
+        _check(self._L.swimm_hip_last_kernel_name(self._ctx, C.c_uint32(q), buf, C.c_size_t(len(buf))))
+        return buf.value.decode()
 
 
 def search_chunks(a, m, a_disp, vc_total: int, chunks, submat, open_gap: int, extend_gap: int, num_gpus: int, vl: int):

@@ -39,3 +39,37 @@ def load_chunks(searcher, chunked, vl):
         searcher.add_chunk(ch["b"], ch["n"], ch["disp"], vl, first)
         first += ch["count"]
     return first
+
+
+def oracle_matrix(w, go=10, ge=2, budget_s=40.0, threads=None):
+    """Score matrix of a workloads.build() dict from the CPU checker: the reference's own AVX2 path
+    (oracle/_ref, cpu_search_avx2_sp CPUsearch.c:482-967) when it was built, else the C restatement.
+    The whole matrix when it fits ~budget_s of the host's cores (about 1 GCUPS per hardware thread), else
+    every k-th sequence.  -> (scores int32 [queries, len(idx)], idx = sorted-database indices scored)"""
+    import os
+    if threads is None:
+        threads = len(os.sched_getaffinity(0))
+    sm = matrix(w["matrix"])
+    cells = float(w["query_residues"]) * float(w["residues"])
+    rate = (1.0e9 if ref.available() else 0.25e9) * threads
+    stride = max(1, int(np.ceil(cells / (rate * budget_s))))
+    idx = np.arange(0, w["n"], stride, dtype=np.int64)
+    if stride == 1:
+        lens, codes = w["lengths"], w["codes"]
+    else:
+        lens = w["lengths"][idx]
+        codes = np.concatenate([w["codes"][w["offs"][i]:w["offs"][i + 1]] for i in idx]) if len(idx) else np.zeros(0, np.int8)
+    # the reference pads odd queries with one dummy residue (code 23, sequences.c:382): scores are unaffected
+    real = w["m"].astype(np.int64)
+    mp = real + (real % 2)
+    dp = np.concatenate([[0], np.cumsum(mp)]).astype(np.uint32)
+    a = np.full(int(mp.sum()), 23, dtype=np.int8)
+    for k in range(len(real)):
+        a[dp[k]:dp[k] + real[k]] = w["a"][w["disp"][k]:w["disp"][k] + real[k]]
+    from swimm_amd import host
+    one = host.assemble_single_chunk(lens, codes, 32, 60)
+    if ref.available():
+        sc, _ = ref.cpu_search(a, mp.astype(np.uint16), dp, one["b"], one["n"], one["nbbs"], one["disp"], sm, go, ge, 32, threads=threads)
+    else:
+        sc = port.search_exact(a, mp.astype(np.uint16), dp, one["b"], one["n"], one["disp"], sm, go, ge, 32, threads=threads)
+    return sc[:, :len(idx)], idx

@@ -1,0 +1,154 @@
+"""BASELINE.json configs c3, c4 and c5 on the GPU against the CPU oracle, at shapes that stress what they stress.
+
+  c3  20 queries (144-5478 aa) x the Swiss-Prot-shaped database AT FULL SIZE (540 080 sequences, 1.96e8 residues, the
+      35 000-residue tail present), BLOSUM50: bulk pipeline + lane-systolic tail on a second stream + chained lane
+      passes + the binary16 -> int16 -> int32 promotion ladder of 20 queries in flight on three streams.
+  c4  the 5478-aa query x 1 000 000 Env-NR-shaped sequences, BLOSUM62: 25 passes through HBM boundary rows.
+  c5  20 queries x an Env-NR-shaped database, PAM250, statically sharded over 8 (virtual) GPUs: every workgroup
+      aligns more than 32 groups back to back (the 32-entry ring of item ids in LDS wraps), the pass-boundary buffer
+      is cut into >= 2 runs, and the per-device top-20 lists are merged on the host.
+
+The checker is the reference's own AVX2 path (oracle/_ref/libswimm_ref.so = cpu_search_avx2_sp, CPUsearch.c:482-967,
+compiled by oracle/Makefile) when it is present, else the C restatement oracle/sw_oracle.c; the WHOLE score matrix is
+compared when the host's cores can produce it in ~40 s, else every k-th sequence (helpers.oracle_matrix).
+Top-r order: utils.c:71-86 (score descending, larger sorted index first).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import matrix, oracle_matrix
+from oracle import port
+from swimm_amd import hip_backend, host, sharding, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(s, chunks):
+    for ch in chunks:
+        s.add_chunk(ch["b"], ch["n"], ch["disp"], 128, ch["first_group"])
+
+
+def _check_matrix(got, want, idx, label):
+    sub = got[:, idx]
+    if not np.array_equal(sub, want):
+        bad = np.argwhere(sub != want)
+        q, k = bad[0]
+        raise AssertionError(f"{label}: {len(bad)} of {want.size} scores differ; first: query {q}, sequence {idx[k]}: "
+                             f"GPU {sub[q, k]} vs oracle {want[q, k]}")
+
+
+def test_c3_swissprot_shape_full_size():
+    w = workloads.build("c3", 1.0)
+    assert w["n"] == 540_080 and int(w["lengths"][-1]) > 30_000 and len(w["m"]) == 20
+    chunks = host.Chunks(w["lengths"], w["codes"], 128, 96 << 20)
+    with hip_backend.HipSearcher(0) as s:
+        s.set_queries(w["a"], w["m"], w["disp"], matrix(w["matrix"]), 10, 2)
+        _load(s, chunks.chunks)
+        got, _ = s.search(chunks.vc * 128)
+        st = s.last_stats()
+        ts, ti, _ = s.search_topr(20, w["n"])
+    chunks.close()
+    want, idx = oracle_matrix(w)
+    _check_matrix(got[:, :w["n"]], want, idx, "c3")
+    assert st["promoted"] >= 1                      # the planted copies of the long queries leave the int16 range (5478 x 5+)
+    for q in range(len(w["m"])):                    # device top-20 == the reference's listing order over the GPU's own vector
+        os_, oi = port.topr(got[q, :w["n"]], 20)
+        assert np.array_equal(ts[q], os_) and np.array_equal(ti[q], oi), q
+
+
+def test_c4_long_query_envnr_shape():
+    w = workloads.build("c4", 0, n_sequences=1_000_000)
+    assert int(w["m"][0]) == 5478 and w["n"] >= 1_000_000
+    chunks = host.Chunks(w["lengths"], w["codes"], 128, 96 << 20)
+    with hip_backend.HipSearcher(0) as s:
+        s.set_queries(w["a"], w["m"], w["disp"], matrix(w["matrix"]), 10, 2)
+        _load(s, chunks.chunks)
+        got, _ = s.search(chunks.vc * 128)
+        plan = s.last_plan(0)
+        # the same recurrence cut differently: 4-wave workgroups (49+ passes), boundary buffer in 3+ runs
+        s.set_option("waves", 4)
+        s.set_option("bnd_mib", 300)
+        other, _ = s.search(chunks.vc * 128)
+    chunks.close()
+    assert plan["passes"] >= 12
+    assert np.array_equal(got, other)
+    want, idx = oracle_matrix(w)
+    _check_matrix(got[:, :w["n"]], want, idx, "c4")
+
+
+def test_c5_envnr_pam250_eight_way_shard(monkeypatch):
+    G = 8
+    w = workloads.build("c5", 0, n_sequences=320_000)
+    sm = matrix(w["matrix"])
+    chunks = host.Chunks(w["lengths"], w["codes"], 128, 2 << 20)
+    assert len(chunks.chunks) >= 3 * G
+    monkeypatch.setenv("SWIMM_HIP_VIRTUAL_GPUS", str(G))      # test hook: device d runs on physical device d % real count
+    assert hip_backend.device_count() >= G
+    owner = sharding.assign_chunks([c["vD"] for c in chunks.chunks], G)
+    q = {"a": w["a"], "m": w["m"], "disp": w["disp"]}
+    got = np.full((len(w["m"]), chunks.vc * 128), -7, dtype=np.int32)
+    lists_s, lists_i = [], []
+    for d in range(G):
+        mine = [c for i, c in enumerate(chunks.chunks) if owner[i] == d]
+        groups = sum(c["count"] for c in mine)
+        cols = sum(int(c["n"].astype(np.int64).sum()) for c in mine)
+        with hip_backend.HipSearcher(d) as s:
+            # four persistent workgroups: each aligns groups / 4 > 32 items back to back; no lane-systolic tail (as at
+            # full size, where no Env-NR group is long beside a CU's load); boundary buffer: two runs
+            s.set_option("wg_limit", 4)
+            s.set_option("tail_mode", 2)
+            s.set_option("bnd_mib", max(1, int(cols * 512 * 0.55) >> 20))
+            s.set_queries(q["a"], q["m"], q["disp"], sm, 10, 2)
+            _load(s, mine)
+            assert groups >= 4 * 40, groups
+            s.search(chunks.vc * 128, out=got)
+            st = s.last_stats()
+            plans = [s.last_plan(k) for k in range(len(w["m"]))]
+            multi = [p["passes"] for p in plans if p["passes"] > 1]
+            assert multi and st["launches"] >= sum(p["passes"] for p in plans) + sum(multi), (st, plans)   # >= 2 boundary runs per multi-pass query
+            s.set_option("wg_limit", 64)                       # (the listing itself does not need the slow four-workgroup shape again)
+            ts, ti, _ = s.search_topr(20, w["n"])
+        lists_s.append(ts)
+        lists_i.append(ti)
+    assert not (got[:, :w["n"]] == -7).any()                   # every sequence was resident on exactly one device
+    want, idx = oracle_matrix(w)
+    _check_matrix(got[:, :w["n"]], want, idx, "c5 (8-way shard)")
+    for k in range(len(w["m"])):                               # host merge of the 8 per-device lists == the reference's listing
+        ms, mi = host.topr_merge(np.stack([l[k] for l in lists_s]), np.stack([l[k] for l in lists_i]), 20)
+        os_, oi = port.topr(got[k, :w["n"]], 20)
+        assert np.array_equal(ms, os_) and np.array_equal(mi, oi), k
+    # the whole-call drop-in (argument list of mic_search_knc_ap_multiple_chunks, MICsearch.h:35-38) over the same 8 devices
+    monkeypatch.setenv("SWIMM_HIP_OPTIONS", "wg_limit=64,tail_mode=2,bnd_mib=4")
+    allsc, _ = hip_backend.search_chunks(w["a"], w["m"], w["disp"], chunks.vc, chunks.chunks, sm, 10, 2, G, 128)
+    assert np.array_equal(allsc[:, :w["n"]], got[:, :w["n"]])
+    chunks.close()
+
+
+def test_c5_ring_wrap_at_natural_occupancy():
+    """4.3 M Env-NR-shaped sequences = 33 000+ groups: with the launch shapes the planner really picks (up to 1 024 persistent
+    workgroups) every workgroup takes more than 32 groups.  No CPU pass over 3.7e13 cells: the dynamic queue must agree
+    with the static partition (no ring at all) on every score, and with the oracle on sampled pairs + every best hit."""
+    w = workloads.build("c5", 0.12)
+    sm = matrix(w["matrix"])
+    chunks = host.Chunks(w["lengths"], w["codes"], 128, 96 << 20)
+    assert chunks.vc >= 33_000
+    with hip_backend.HipSearcher(0) as s:
+        s.set_queries(w["a"], w["m"], w["disp"], sm, 10, 2)
+        _load(s, chunks.chunks)
+        dyn, _ = s.search(chunks.vc * 128)
+        ts, ti, _ = s.search_topr(20, w["n"])
+        s.set_option("dynamic", 0)
+        sta, _ = s.search(chunks.vc * 128)
+    chunks.close()
+    assert np.array_equal(dyn, sta)
+    rng = np.random.default_rng(5)
+    picks = [(int(rng.integers(len(w["m"]))), int(rng.integers(w["n"]))) for _ in range(150)]
+    picks += [(k, int(ti[k, 0])) for k in range(len(w["m"]))]
+    for k, i in picks:
+        qa = w["a"][w["disp"][k]:w["disp"][k + 1]]
+        assert dyn[k, i] == port.pair_score(qa, w["codes"][w["offs"][i]:w["offs"][i + 1]], sm, 10, 2), (k, i)
+    for k in range(len(w["m"])):
+        os_, oi = port.topr(dyn[k, :w["n"]], 20)
+        assert np.array_equal(ts[k], os_) and np.array_equal(ti[k], oi), k

@@ -3,9 +3,9 @@
 the CPU oracle (a full oracle pass would take minutes on the test box):
 
   * decomposition invariance -- the score vector does not depend on how the DP is cut into strips /
-    waves / passes / kernels (rows_per_wave 16 vs 32, single-wave workgroups, every group through the
-    lane-systolic kernel, binary16 first tier): six different schedules of the same recurrence must agree bit for bit on
-    all 1 000 004 scores;
+    waves / passes / kernels (rows_per_wave 16, single-wave workgroups, every group through the lane-systolic kernel,
+    packed-int16 first tier, static partition instead of the dynamic queue, 4-wave workgroups with the boundary buffer cut
+    into a dozen runs): seven different schedules of the same recurrence must agree bit for bit on all 1 000 004 scores;
   * known answers -- the planted exact copy scores the query's self score, mutated copies score less,
     in order of mutation rate;
   * sampled oracle -- 400 randomly chosen sequences + the top-20 against sw_oracle_pair;
@@ -46,7 +46,8 @@ def test_c2_full_size(c2):
     shard, chunks = c2
     assert shard["n"] == 1_000_004 and 5.9e8 < shard["residues"] < 6.1e8
     base, top = _search(shard, chunks, {}, topr=True)
-    for opts in ({"rows_per_wave": 16}, {"max_waves": 1}, {"tail_mode": 1}, {"f16": 1}, {"f16": 1, "rows_per_wave": 24}):
+    for opts in ({"rows_per_wave": 16}, {"max_waves": 1}, {"tail_mode": 1}, {"f16": 0}, {"dynamic": 0},
+                 {"bnd_mib": 64, "rows_per_wave": 16, "waves": 4}):
         other, _ = _search(shard, chunks, opts)
         assert np.array_equal(base, other), opts
     sm = submat.table("blosum62")

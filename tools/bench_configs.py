@@ -21,43 +21,9 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from swimm_amd import hip_backend, host, submat, synth  # noqa: E402
 
-CFG = {
-    "c2": dict(lengths="c2", queries=[3], matrix="blosum62"),
-    "c2long": dict(lengths="c2", queries=[19], matrix="blosum62"),
-    "c3": dict(lengths="c3", queries=list(range(20)), matrix="blosum50"),
-    "c4": dict(lengths="c4", queries=[19], matrix="blosum62"),
-    "c5": dict(lengths="c5", queries=list(range(20)), matrix="pam250"),
-    "c3clip": dict(lengths="c3", queries=list(range(20)), matrix="blosum50", clip=3000),   # c3 without its long-sequence tail
-}
+from swimm_amd import workloads  # noqa: E402
 
-
-def build(cfg, scale, seed):
-    qs_all = synth.make_queries(seed)
-    qs = [qs_all[i] for i in cfg["queries"]]
-    base = synth.config_lengths(cfg["lengths"], scale)
-    if cfg.get("clip"):
-        base = np.minimum(base, cfg["clip"])
-    planted = synth.planted_homologs(seed, qs)
-    lens = np.concatenate([base, np.array([len(s) for _, s in planted], dtype=np.int64)])
-    order = np.argsort(lens, kind="stable")
-    L = lens[order].astype(np.uint16)
-    total = int(lens.sum())
-    codes = np.empty(total, dtype=np.int8)
-    blk = 1 << 26
-    for s in range(0, total, blk):
-        e = min(total, s + blk)
-        codes[s:e] = host.recode(synth.residues(seed, 7, s, e - s))
-    offs = np.concatenate([[0], np.cumsum(L.astype(np.int64))])
-    pos_of = np.empty(len(lens), dtype=np.int64)
-    pos_of[order] = np.arange(len(lens))
-    for k, (_, seq) in enumerate(planted):
-        p = pos_of[len(base) + k]
-        codes[offs[p]:offs[p] + len(seq)] = host.recode(seq)
-    qorder = np.argsort([len(s) for _, s in qs], kind="stable")
-    qa = [host.recode(qs[i][1]) for i in qorder]
-    m = np.array([len(x) for x in qa], dtype=np.uint16)
-    disp = np.concatenate([[0], np.cumsum(m)]).astype(np.uint32)
-    return L, codes, offs, np.concatenate(qa), m, disp
+CFG = workloads.CONFIGS
 
 
 def main():
@@ -74,10 +40,9 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="key=value for swimm_hip_set_option (repeatable)")
     args = ap.parse_args()
     cfg = dict(CFG[args.config])
-    if args.only:
-        cfg["queries"] = [cfg["queries"][int(i)] for i in args.only.split(",")]
     t0 = time.time()
-    L, codes, offs, a, m, disp = build(cfg, args.scale, {"c2": 2, "c2long": 2, "c3": 3, "c4": 5, "c5": 5, "c3clip": 3}[args.config])
+    w = workloads.build(args.config, args.scale, queries=[int(i) for i in args.only.split(",")] if args.only else None)
+    L, codes, offs, a, m, disp = w["lengths"], w["codes"], w["offs"], w["a"], w["m"], w["disp"]
     chunks = host.Chunks(L, codes, 128, 96 << 20)
     residues = int(L.astype(np.int64).sum())
     print(f"# {args.config} scale {args.scale}: {len(L)} sequences, {residues} residues, {len(m)} queries (sum {int(m.sum())} aa), "

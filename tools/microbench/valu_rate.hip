@@ -71,6 +71,20 @@ DEFINE_KERNEL(pk_mul_f16, "v_pk_mul_f16 %0, %0, %1")
 DEFINE_KERNEL(pk_min_f16, "v_pk_min_f16 %0, %0, %1")
 DEFINE_KERNEL(pk_add_u16, "v_pk_add_u16 %0, %0, %1")
 DEFINE_KERNEL(dot2c_i32_i16, "v_dot2c_i32_i16 %0, %1, %2")
+// third batch (round 2): ways to build the packed (A, B) score pair without the half-rate v_perm_b32
+DEFINE_KERNEL(pack_b32_f16, "v_pack_b32_f16 %0, %0, %1")
+DEFINE_KERNEL(pack_b32_f16_hi, "v_pack_b32_f16 %0, %0, %1 op_sel:[1,1,0]")
+DEFINE_KERNEL(add_f16_sdwa_keep, "v_add_f16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0")
+DEFINE_KERNEL(add_f16_sdwa_pad, "v_add_f16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0")
+DEFINE_KERNEL(add_f16_sdwa_src, "v_add_f16_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1")
+DEFINE_KERNEL(bfi_b32, "v_bfi_b32 %0, %1, %0, %2")
+DEFINE_KERNEL(and_or_b32, "v_and_or_b32 %0, %0, %1, %2")
+DEFINE_KERNEL(lshl_or_b32, "v_lshl_or_b32 %0, %0, 16, %1")
+DEFINE_KERNEL(alignbit_b32, "v_alignbit_b32 %0, %0, %1, 16")
+DEFINE_KERNEL(add_i16_opsel, "v_add_i16 %0, %0, %1 op_sel:[1,0,1]")
+DEFINE_KERNEL(fma_f16_opsel, "v_fma_f16 %0, %0, 1.0, %1 op_sel:[1,0,0,1]")
+DEFINE_KERNEL(mov_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+DEFINE_KERNEL(cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
 
 typedef void (*kern_t)(uint32_t *, uint32_t);
 struct Entry { const char *name; kern_t k; };
@@ -90,6 +104,11 @@ int main()
         {"v_add_u16", k_add_u16}, {"v_sub_u16", k_sub_u16}, {"v_max_u16", k_max_u16}, {"v_mul_u32_u24", k_mul_u32_u24},
         {"v_sub_u32", k_sub_u32}, {"v_pk_mul_f16", k_pk_mul_f16}, {"v_pk_min_f16", k_pk_min_f16}, {"v_pk_add_u16", k_pk_add_u16},
         {"v_dot2c_i32_i16", k_dot2c_i32_i16},
+        {"v_pack_b32_f16", k_pack_b32_f16}, {"v_pack_b32_f16 hi", k_pack_b32_f16_hi}, {"v_add_f16_sdwa keep", k_add_f16_sdwa_keep},
+        {"v_add_f16_sdwa pad", k_add_f16_sdwa_pad}, {"v_add_f16_sdwa src", k_add_f16_sdwa_src}, {"v_bfi_b32", k_bfi_b32},
+        {"v_and_or_b32", k_and_or_b32}, {"v_lshl_or_b32", k_lshl_or_b32}, {"v_alignbit_b32", k_alignbit_b32},
+        {"v_add_i16 op_sel", k_add_i16_opsel}, {"v_fma_f16 op_sel", k_fma_f16_opsel}, {"v_mov_b32_dpp", k_mov_dpp},
+        {"v_cndmask_b32", k_cndmask},
     };
     if (getenv("VALU_RATE_FROM")) ks.erase(ks.begin(), ks.begin() + atoi(getenv("VALU_RATE_FROM")));
     hipDeviceProp_t prop;

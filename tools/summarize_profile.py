@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses gpurun_out/prof_<tag>/ (written by tools/profile_bench.sh) into the files under profiles/.
 
-usage: python tools/summarize_profile.py <tag> [round-prefix, default r01]
+usage: python tools/summarize_profile.py <tag> [round-prefix, default r02]
   profiles/<rnd>_c2_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied)
   profiles/<rnd>_c2_pmc_summary.csv    per-counter mean per launch of the dominant kernel
   profiles/<rnd>_pmc_traffic.json      HBM bytes per launch with the gfx950 corrections
@@ -24,7 +24,7 @@ def find(base, pat):
 
 def main():
     tag = sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
     base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = os.path.join(ROOT, "profiles")
 
@@ -60,12 +60,24 @@ def main():
         v = list(per[c].values())
         return sum(v) / len(v) if v else None
 
+    # the configuration and launch plan the profiled command ran with: from its own JSON line (kt.log)
+    line = {}
+    try:
+        for l in open(os.path.join(base, "kt.log")):
+            if l.startswith("{"):
+                line = json.loads(l)
+    except OSError:
+        pass
+    cfg = line.get("config", {})
     fetch, write = mean("FETCH_SIZE"), mean("WRITE_SIZE")
     if fetch is not None and write is not None:
         traffic = {
+            "workload_key": (cfg.get("workload", "c2").split(":")[0]), "scale": cfg.get("scale", 1.0), "plan": cfg.get("plan"),
+            "sq_insts_valu_per_launch": mean("SQ_INSTS_VALU"),
+            "kernel_avg_ns": float(rows[0]["AverageNs"]), "kernel_calls": int(rows[0]["Calls"]),
             "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE, separate passes (profiles/{rnd}_c2_pmc_summary.csv)",
             "kernel": dominant,
-            "workload": "bench.py c2, 1M sequences, 375-aa query",
+            "workload": cfg.get("workload", "bench.py c2, 1M sequences, 375-aa query"),
             "FETCH_SIZE_KB": fetch,
             "WRITE_SIZE_KB": write,
             "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on coalesced streaming reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact. The guide calibrates 16 B/lane; this kernel loads 8 B/lane (dwordx2), calibrated here on its known byte counts: x2 reproduces them within 3 % in the one-pass launch (DB bytes only) and within 1 % in the two-pass launch (DB + boundary bytes)",

@@ -125,6 +125,10 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *   "lane_rows"      1 = default: one-pass lane-systolic launches of short queries use 2 / 4 query rows per lane; 0 = always 8
  *   "split"          1 = default: a query of three or more passes runs the even- and odd-ranked groups as two kernels on two streams,
  *                    so that the end of one launch is covered by the other; 0 = one kernel per pass
+ *   "lazy_upload"    0 = default: add_chunk / add_sequences copy the caller's buffers before they return; 1 = they only
+ *                    record them and the next search streams the chunks in, copying and tiling chunk k+1 while chunk k
+ *                    is being aligned (the double-buffered transfer of MICsearch.c:85-91) -- the buffers must then stay
+ *                    valid until that search has returned.  swimm_hip_search_chunks always works this way.
  *   "lane_acquire"   0 = default: chained lane-systolic passes read their predecessor's boundary rows with sc1 loads behind a
  *                    relaxed poll; 1 = an agent-scope acquire after every poll as well (A/B option)
  *   "score_mib"      HBM budget of the score rows (4 B per query and sequence): the query list is walked in batches

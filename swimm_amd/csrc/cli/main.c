@@ -137,6 +137,9 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
         const double t0 = swimm_wtime();
         if (!bad && api->create(g, &ctx)) bad = 1;
         const double t1 = swimm_wtime();
+        /* the preprocessed database stays in host memory for the whole run: slabs stream in while the search runs
+         * (transfer overlapped with compute, MICsearch.c:85-91) */
+        if (!bad && api->set_option(ctx, "lazy_upload", 1)) bad = 1;
         if (!bad && api->set_queries(ctx, q->a, q->m, q->disp, (uint32_t)q->count, submat, o->open_gap, o->extend_gap)) bad = 1;
         for (uint32_t c = 0; !bad && c < n_slabs; ++c)
             if (slabs[c].owner == g && api->add_sequences(ctx, lengths + slabs[c].first, codes + slabs[c].offset, slabs[c].count,

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <cxxabi.h>
 #include <map>
 #include <queue>
@@ -105,9 +106,23 @@ struct LaneScratch {
 
 struct ChunkRec {
     uint8_t *d_tiled = nullptr;
+    uint32_t *d_len = nullptr;  // chunk-layout chunks: every slot's true length, written by the re-tile kernel
     uint64_t first_seq = 0;     // global sorted index of the chunk's first sequence
     uint64_t n_seq = 0;         // group_count * vl
     uint32_t group0 = 0, n_groups = 0;
+    uint64_t cols = 0;          // padded columns of the chunk's device groups
+    // upload source: the caller's buffers.  Eager mode (default) copies inside add_chunk / add_sequences; with the
+    // option "lazy_upload" they are only recorded and the first search streams them in (X2 overlapped with compute,
+    // MICsearch.c:85-91), so they must stay valid until that search has returned.
+    int kind = 0;               // 0 = reference chunk layout (re-tile), 1 = .seq slab (tile)
+    const char *h_b = nullptr; uint64_t vD = 0; const uint16_t *h_n = nullptr; const uint32_t *h_disp = nullptr;
+    uint32_t group_count = 0, vl = 0;
+    const char *h_codes = nullptr; uint64_t code_bytes = 0;
+    std::vector<uint32_t> off;  // kind 1: residue offset of every sequence (n_seq + 1)
+    std::vector<uint64_t> goff; // byte offset of every device group in d_tiled
+    std::vector<uint32_t> gcols;
+    bool uploaded = false, lens_known = false;
+    hipEvent_t ready = nullptr; // recorded on the upload stream behind the chunk's (re-)tile kernel
 };
 
 struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true; };
@@ -121,6 +136,10 @@ struct swimm_hip_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     hipStream_t stream2 = nullptr;      // lane-systolic tail runs beside the bulk kernel
     hipEvent_t ev_tail = nullptr;
+    hipStream_t stream_up = nullptr;    // uploads: H2D copies, (re-)tile kernels, work lists -- never waits for a DP kernel
+    hipEvent_t ev_copied = nullptr;
+    DevBuf<uint8_t> up_b; DevBuf<uint16_t> up_n; DevBuf<uint32_t> up_disp, up_gcols, up_off; DevBuf<uint64_t> up_goff;   // upload scratch, reused chunk after chunk
+    int opt_lazy_upload = 0;            // 1: add_chunk / add_sequences record the caller's buffers, the first search streams them in
     hipStream_t stream3 = nullptr;      // promotion re-runs
     hipEvent_t ev_ready = nullptr, ev_tail3 = nullptr;
     std::vector<hipEvent_t> ev_query;   // [2q] bulk done, [2q+1] tail done
@@ -209,7 +228,12 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
     return 0;
 }
 
-std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, int n_wg);
+// a run of consecutive device groups that is searched as one unit: the whole resident database (work lists cached),
+// or one chunk of a database that is still streaming in
+struct Range { uint32_t g0 = 0, g1 = 0; uint64_t cols = 0; };
+Range whole_range(const swimm_hip_ctx *c) { Range r; r.g0 = 0; r.g1 = (uint32_t)c->groups.size(); r.cols = c->total_cols; return r; }
+
+std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg);
 
 // persistent workgroups of a pipeline launch: what the chip holds, unless the caller caps it
 int n_workgroups(const swimm_hip_ctx *c, int per_cu)
@@ -226,7 +250,7 @@ double plan_imbalance(swimm_hip_ctx *c, int n_wg)
 {
     auto it = c->imbalance_cache.find(n_wg);
     if (it != c->imbalance_cache.end()) return it->second;
-    const std::vector<uint8_t> is_tail = pick_tail(c, n_wg);
+    const std::vector<uint8_t> is_tail = pick_tail(c, whole_range(c));
     std::vector<uint32_t> cols;
     uint64_t total = 0;
     for (uint32_t g = 0; g < c->groups.size(); ++g)
@@ -371,18 +395,18 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
             }
         }
         HIP_TRY(pl.split_items.reserve(split.size()));
-        HIP_TRY(hipMemcpyAsync(pl.split_items.p, split.data(), split.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));   // `split` dies here
+        HIP_TRY(hipMemcpyAsync(pl.split_items.p, split.data(), split.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream_up));
+        HIP_TRY(hipStreamSynchronize(c->stream_up));   // `split` dies here
     }
     HIP_TRY(pl.queue_items.reserve(sorted.size()));
-    HIP_TRY(hipMemcpyAsync(pl.queue_items.p, sorted.data(), sorted.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(pl.queue_items.p, sorted.data(), sorted.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream_up));
     HIP_TRY(pl.items.reserve(items.size()));
     HIP_TRY(pl.wg_first.reserve(first.size()));
     HIP_TRY(pl.wg_chunks.reserve(chunks.size()));
-    HIP_TRY(hipMemcpyAsync(pl.items.p, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(pl.wg_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(pl.wg_chunks.p, chunks.data(), chunks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // the host vectors die here
+    HIP_TRY(hipMemcpyAsync(pl.items.p, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream_up));
+    HIP_TRY(hipMemcpyAsync(pl.wg_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream_up));
+    HIP_TRY(hipMemcpyAsync(pl.wg_chunks.p, chunks.data(), chunks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream_up));
+    HIP_TRY(hipStreamSynchronize(c->stream_up));   // the host vectors die here
     return 0;
 }
 
@@ -399,8 +423,8 @@ int upload_lane_items(swimm_hip_ctx *c, std::vector<LaneItem> &v, LaneList &ll)
     ll.cols = cols;
     ll.cell_cols = cols;
     HIP_TRY(ll.items.reserve(v.size()));
-    HIP_TRY(hipMemcpyAsync(ll.items.p, v.data(), v.size() * sizeof(LaneItem), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(ll.items.p, v.data(), v.size() * sizeof(LaneItem), hipMemcpyHostToDevice, c->stream_up));
+    HIP_TRY(hipStreamSynchronize(c->stream_up));
     return 0;
 }
 
@@ -408,42 +432,43 @@ int upload_lane_items(swimm_hip_ctx *c, std::vector<LaneItem> &v, LaneList &ll)
 // one workgroup, so any group longer than a fraction of the mean per-workgroup load would set the
 // kernel's makespan (Swiss-Prot's 35 000-residue titin against a 360-residue mean).  Longest first, move
 // groups while ncols > tail_alpha * (remaining columns / n_wg).
-std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, int n_wg)
+std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> flag per group of the range
 {
-    std::vector<uint8_t> is_tail(c->groups.size(), 0);
+    const uint32_t n = rg.g1 - rg.g0;
+    std::vector<uint8_t> is_tail(n, 0);
     if (c->opt_tail_mode == 2) return is_tail;                        // never
     if (c->opt_tail_mode == 1) { std::fill(is_tail.begin(), is_tail.end(), 1); return is_tail; }   // always
-    std::vector<uint32_t> order(c->groups.size());
-    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->groups[a].ncols > c->groups[b].ncols; });
-    uint64_t rest = c->total_cols;
-    (void)n_wg;   // the yardstick is the load of a CU, however many workgroups share it
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->groups[rg.g0 + a].ncols > c->groups[rg.g0 + b].ncols; });
+    uint64_t rest = rg.cols;
+    // the yardstick is the load of a CU, however many workgroups share it
     for (uint32_t g : order) {
         const double mean = (double)rest / c->num_cu;
-        if ((double)c->groups[g].ncols <= c->opt_tail_frac * 0.01 * mean) break;
+        if ((double)c->groups[rg.g0 + g].ncols <= c->opt_tail_frac * 0.01 * mean) break;
         is_tail[g] = 1;
-        rest -= c->groups[g].ncols;
+        rest -= c->groups[rg.g0 + g].ncols;
     }
     return is_tail;
 }
 
-int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool whole_db, DbPlan **out)
+// work lists of one range for launches of n_wg workgroups: the pipeline kernel's items and the lane-systolic tail
+int make_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool no_tail, const Range &rg, bool exact_lengths, DbPlan &dp)
 {
-    const int key = n_wg | (mode == Mode::I32 ? (1 << 30) : 0) | (whole_db ? (1 << 29) : 0);   // packed int16 and f16 share plans
-    auto it = c->plans.find(key);
-    if (it != c->plans.end()) { *out = &it->second; return 0; }
     std::vector<WorkUnit> units;
     std::vector<LaneItem> tail;
     uint64_t bnd_cols = 0;
+    const uint64_t col0 = rg.g0 < c->group_col_off.size() ? c->group_col_off[rg.g0] : 0;
     if (mode != Mode::I32) {
-        std::vector<uint8_t> is_tail = pick_tail(c, n_wg);
-        if (whole_db) std::fill(is_tail.begin(), is_tail.end(), 0);   // every group through the pipeline kernel
-        for (uint32_t g = 0; g < c->groups.size(); ++g) {
+        std::vector<uint8_t> is_tail = pick_tail(c, rg);
+        if (no_tail) std::fill(is_tail.begin(), is_tail.end(), 0);   // every group through the pipeline kernel
+        for (uint32_t g = rg.g0; g < rg.g1; ++g) {
             const GroupDesc &gd = c->groups[g];
-            if (!is_tail[g]) { units.push_back(WorkUnit{g, 0, 0, gd.ncols, c->group_col_off[g]}); continue; }
+            if (!is_tail[g - rg.g0]) { units.push_back(WorkUnit{g, 0, 0, gd.ncols, c->group_col_off[g] - col0}); continue; }
             for (uint32_t l = 0; l < 64; ++l) {
-                // a pair only runs to the end of its longer member, not to the end of the group
-                const uint32_t len = std::max(c->seq_len[gd.seq0 + l], c->seq_len[gd.seq0 + 64 + l]);
+                // a pair only runs to the end of its longer member, not to the end of the group (when the lengths are
+                // already known: a chunk that is still streaming in runs to the end of its group -- padding scores 0)
+                const uint32_t len = exact_lengths ? std::max(c->seq_len[gd.seq0 + l], c->seq_len[gd.seq0 + 64 + l]) : gd.ncols;
                 if (len == 0) continue;                 // empty pair: scores stay 0
                 LaneItem li{};
                 li.db = gd.db; li.lane = l; li.half = 0; li.ncols = (len + kChunkCols - 1) / kChunkCols * kChunkCols;
@@ -451,21 +476,31 @@ int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool whole_db, DbPlan **o
                 tail.push_back(li);
             }
         }
-        bnd_cols = c->total_cols;
+        bnd_cols = rg.cols;
     } else {
-        for (uint32_t g = 0; g < c->groups.size(); ++g)
+        for (uint32_t g = rg.g0; g < rg.g1; ++g)
             for (uint32_t h = 0; h < 2; ++h)
                 units.push_back(WorkUnit{g, h, c->groups[g].seq0 / 64 + h, c->groups[g].ncols,
-                                         2 * c->group_col_off[g] + (uint64_t)h * c->groups[g].ncols});
-        bnd_cols = 2 * c->total_cols;
+                                         2 * (c->group_col_off[g] - col0) + (uint64_t)h * c->groups[g].ncols});
+        bnd_cols = 2 * rg.cols;
     }
-    DbPlan &dp = c->plans[key];
     if (!units.empty()) {
         if (build_plan(c, units, n_wg, dp.main)) return 1;
         dp.main.bnd_cols = bnd_cols;
         dp.have_main = true;
     }
     if (!tail.empty() && upload_lane_items(c, tail, dp.tail)) return 1;
+    return 0;
+}
+
+// the resident database's work lists, cached per launch shape
+int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool whole_db, DbPlan **out)
+{
+    const int key = n_wg | (mode == Mode::I32 ? (1 << 30) : 0) | (whole_db ? (1 << 29) : 0);   // packed int16 and f16 share plans
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) { *out = &it->second; return 0; }
+    DbPlan &dp = c->plans[key];
+    if (make_db_plan(c, mode, n_wg, whole_db, whole_range(c), true, dp)) return 1;
     *out = &dp;
     return 0;
 }
@@ -510,14 +545,14 @@ static bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &p
 }
 
 // `st`: stream of the one-kernel-per-pass path (one-pass queries rotate over three streams)
-int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st)
+int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st, bool allow_split)
 {
     std::vector<std::pair<uint32_t, uint32_t>> segs;
     uint64_t seg_cols = pl.bnd_cols;
     if (c->opt_dynamic && qp.passes > 1) boundary_segments(c, pl, segs, &seg_cols);
     else segs.push_back({0u, pl.n_items});
     if (qp.passes > 1) HIP_TRY(c->d_bnd.reserve(seg_cols * 64));
-    if (use_split(c, qp, pl, segs.size())) {
+    if (allow_split && use_split(c, qp, pl, segs.size())) {
         HIP_TRY(hipEventRecord(c->ev_a, c->stream));               // stream B joins after everything queued so far
         HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_a, 0));
         // every kernel asks for the full complement of workgroups: the two kernels of a pass share the CUs while both
@@ -669,6 +704,98 @@ int refresh_plans(swimm_hip_ctx *c)
     return 0;
 }
 
+// Registers a chunk's device groups (geometry only: nothing is copied here).
+int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> &lens_or_empty)
+{
+    const uint32_t dev_groups = rec.n_groups;
+    uint64_t bytes = 0;
+    for (uint32_t g = 0; g < dev_groups; ++g) { rec.goff[g] = bytes; bytes += (uint64_t)rec.gcols[g] * kGroupSeqs; }
+    HIP_TRY(hipMalloc((void **)&rec.d_tiled, std::max<uint64_t>(bytes, 16)));
+    if (rec.kind == 0) {
+        hipError_t e = hipMalloc((void **)&rec.d_len, (size_t)dev_groups * kGroupSeqs * sizeof(uint32_t));
+        if (e != hipSuccess) { (void)hipFree(rec.d_tiled); rec.d_tiled = nullptr; return fail("hipMalloc(sequence lengths): %s", hipGetErrorString(e)); }
+    }
+    if (hipEventCreateWithFlags(&rec.ready, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(rec.d_tiled); (void)hipFree(rec.d_len);
+        return fail("hipEventCreate failed");
+    }
+    rec.group0 = (uint32_t)c->groups.size();
+    rec.cols = 0;
+    for (uint32_t g = 0; g < dev_groups; ++g) {
+        GroupDesc gd;
+        gd.db = rec.d_tiled + rec.goff[g];
+        gd.ncols = rec.gcols[g];
+        gd.seq0 = (uint32_t)((rec.group0 + g) * kGroupSeqs);
+        c->groups.push_back(gd);
+        c->group_col_off.push_back(c->total_cols);
+        c->total_cols += rec.gcols[g];
+        rec.cols += rec.gcols[g];
+    }
+    const size_t base = c->seq_len.size();
+    c->seq_len.resize(base + (size_t)dev_groups * kGroupSeqs, 0);
+    for (size_t i = 0; i < lens_or_empty.size(); ++i) c->seq_len[base + i] = lens_or_empty[i];
+    rec.lens_known = rec.kind == 1;
+    c->chunks.push_back(std::move(rec));
+    c->groups_dirty = true;
+    release_plans(c);
+    return 0;
+}
+
+// X2 (MICsearch.c:85-88): one chunk's bytes to the device and into device groups, all on the upload stream.  The
+// copies come from pageable memory, so every hipMemcpyAsync returns only when its source has been consumed; what
+// stays asynchronous is the (re-)tile kernel, whose end `ready` marks.  Scratch is reused chunk after chunk (the
+// stream is in order: the next chunk's copy cannot overtake this chunk's kernel).
+int upload_chunk(swimm_hip_ctx *c, ChunkRec &r)
+{
+    if (r.uploaded) return 0;
+    hipStream_t s = c->stream_up;
+    const uint32_t dev_groups = r.n_groups;
+    HIP_TRY(c->up_gcols.reserve(dev_groups));
+    HIP_TRY(c->up_goff.reserve(dev_groups));
+    HIP_TRY(hipMemcpyAsync(c->up_gcols.p, r.gcols.data(), dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->up_goff.p, r.goff.data(), dev_groups * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    if (r.kind == 0) {
+        HIP_TRY(c->up_b.reserve(std::max<uint64_t>(r.vD, 16)));
+        HIP_TRY(c->up_n.reserve(r.group_count));
+        HIP_TRY(c->up_disp.reserve(r.group_count));
+        HIP_TRY(hipMemsetAsync(r.d_len, 0, (size_t)dev_groups * kGroupSeqs * sizeof(uint32_t), s));
+        HIP_TRY(hipMemcpyAsync(c->up_n.p, r.h_n, r.group_count * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->up_disp.p, r.h_disp, r.group_count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_b, r.vD, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(c->ev_copied, s));
+        HIP_TRY(launch_retile(c->up_b.p, c->up_n.p, c->up_disp.p, r.group_count, r.vl, c->up_goff.p, c->up_gcols.p, dev_groups, r.d_tiled, r.d_len, s));
+    } else {
+        HIP_TRY(c->up_b.reserve(std::max<uint64_t>(r.code_bytes, 16)));
+        HIP_TRY(c->up_off.reserve(r.off.size()));
+        HIP_TRY(hipMemcpyAsync(c->up_off.p, r.off.data(), r.off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_codes, r.code_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(c->ev_copied, s));
+        HIP_TRY(launch_tile_sequences(c->up_b.p, c->up_off.p, (uint32_t)r.n_seq, c->up_goff.p, c->up_gcols.p, dev_groups, r.d_tiled, s));
+    }
+    HIP_TRY(hipEventRecord(r.ready, s));
+    HIP_TRY(hipEventSynchronize(c->ev_copied));      // the caller's buffers have been read
+    r.uploaded = true;
+    r.h_b = nullptr; r.h_n = nullptr; r.h_disp = nullptr; r.h_codes = nullptr;
+    std::vector<uint32_t>().swap(r.off);
+    return 0;
+}
+
+// true lengths of the chunk-layout chunks' slots come from the re-tile kernel: fetched when somebody needs them
+// (lane-systolic work lists, promotion re-runs), not inside add_chunk
+int sync_lengths(swimm_hip_ctx *c)
+{
+    bool any = false;
+    for (ChunkRec &r : c->chunks) {
+        if (r.lens_known || !r.uploaded) continue;
+        HIP_TRY(hipMemcpyAsync(c->seq_len.data() + (size_t)r.group0 * kGroupSeqs, r.d_len, (size_t)r.n_groups * kGroupSeqs * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, c->stream_up));
+        r.lens_known = true;
+        any = true;
+    }
+    if (any) HIP_TRY(hipStreamSynchronize(c->stream_up));
+    return 0;
+}
+
 // device part of a search for the queries [qb, qe) (ascending-length order of set_queries): leaves exact scores in
 // d_scores[(q - qb) * S + local_slot].  The callers walk the query list in batches whose score rows fit the
 // `score_mib` budget.
@@ -686,17 +813,45 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     const uint64_t S = (uint64_t)c->groups.size() * kGroupSeqs;
     *slots_out = S;
 
+    // Chunks whose bytes are still on the host (option "lazy_upload"): this search streams them in -- chunk k+1 is
+    // copied and tiled on the upload stream while chunk k is being aligned (X2 overlapped with compute,
+    // MICsearch.c:85-91) -- and every chunk is then one range with work lists of its own.  Otherwise the whole resident
+    // database is one range with cached work lists.
+    bool streaming = false;
+    for (const ChunkRec &r : c->chunks) streaming = streaming || !r.uploaded;
+    std::vector<Range> ranges;
+    if (streaming) {
+        uint64_t mb = 16, mn = 1, mg = 1, mo = 1;
+        for (const ChunkRec &r : c->chunks) {
+            Range rg; rg.g0 = r.group0; rg.g1 = r.group0 + r.n_groups; rg.cols = r.cols; ranges.push_back(rg);
+            if (r.uploaded) continue;
+            mb = std::max<uint64_t>(mb, r.kind == 0 ? r.vD : r.code_bytes); mn = std::max<uint64_t>(mn, r.group_count);
+            mg = std::max<uint64_t>(mg, r.n_groups); mo = std::max<uint64_t>(mo, r.off.size());
+        }
+        // the upload scratch grows now, not between two chunks (growing frees the old buffer)
+        HIP_TRY(c->up_b.reserve(mb)); HIP_TRY(c->up_n.reserve(mn)); HIP_TRY(c->up_disp.reserve(mn));
+        HIP_TRY(c->up_gcols.reserve(mg)); HIP_TRY(c->up_goff.reserve(mg)); HIP_TRY(c->up_off.reserve(mo));
+    } else {
+        if (sync_lengths(c)) return 1;
+        ranges.push_back(whole_range(c));
+    }
+    std::vector<std::map<int, DbPlan>> stream_plans(streaming ? ranges.size() : 0);   // released when the search has drained
+    auto release_stream_plans = [&]() {
+        for (auto &m : stream_plans) for (auto &kv : m) { kv.second.main.release(); kv.second.tail.release(); }
+        stream_plans.clear();
+    };
+    struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{[&]() { if (streaming) { (void)hipDeviceSynchronize(); release_stream_plans(); } }};
+
     // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
     // query's end are zero, like the reference's dummy row 23
     const Mode main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 ? Mode::F16 : Mode::PK16);
     // a database with a long-sequence tail is searched with launch shapes that leave room for lane-systolic waves
     bool lane_room = false;
-    if (c->opt_tail_mode != 2 && main_mode != Mode::I32) {
-        uint32_t longest = 0;
-        for (const GroupDesc &g : c->groups) longest = std::max(longest, g.ncols);
-        lane_room = c->opt_tail_mode == 1 || (double)longest > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
-    }
+    uint32_t longest_cols = 0;
+    for (const GroupDesc &g : c->groups) longest_cols = std::max(longest_cols, g.ncols);
+    if (c->opt_tail_mode != 2 && main_mode != Mode::I32)
+        lane_room = c->opt_tail_mode == 1 || (double)longest_cols > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
     std::vector<QueryPlan> qps(qn);
     std::vector<uint8_t> rotated(qn, 0);
     uint32_t n_short = 0;
@@ -704,9 +859,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     // (with a handful of short queries the last ones' chains would stick out at the end of the search; and a database
     // with an extreme sequence -- c3's 35 000 residues are 6x a CU's mean load -- keeps the tail kernel, whose chain
     // is 3.6x faster per column than a 4-wave workgroup's)
-    uint32_t longest_cols = 0;
-    for (const GroupDesc &g : c->groups) longest_cols = std::max(longest_cols, g.ncols);
-    const bool many_short = n_short >= 8;
+    const bool many_short = n_short >= 8 && !streaming;
     const bool rotate = many_short && (double)longest_cols <= 2.0 * (double)c->total_cols / c->num_cu;
     size_t prof_elems = 0;
     for (uint32_t q = 0; q < qn; ++q) {
@@ -718,7 +871,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             rotated[q] = choose_plan(c, main_mode, qm[q], false, true, &qps[q]) == 0;   // fails when no one-pass shape exists
         }
         if (!rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;
-        if (getenv("SWIMM_HIP_DEBUG"))
+        if (dbg)
             fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
         const uint32_t lane_rows = (uint32_t)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
         qps[q].mpad = std::max(qps[q].mpad, lane_rows);
@@ -740,32 +893,48 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
     HIP_TRY(hipMemsetAsync(c->d_scores.p, 0, (size_t)qn * S * sizeof(int32_t), c->stream));
 
+    // the work lists of a (range, launch shape): cached for the resident database, temporary for a streaming chunk
+    auto plan_of = [&](size_t ri, uint32_t q, DbPlan **out) -> int {
+        int per_cu = 1;
+        if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
+        const int n_wg = n_workgroups(c, per_cu);
+        if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0, out);
+        auto it = stream_plans[ri].find(n_wg);
+        if (it == stream_plans[ri].end()) {
+            DbPlan &dp = stream_plans[ri][n_wg];
+            if (make_db_plan(c, main_mode, n_wg, false, ranges[ri], c->chunks[ri].lens_known, dp)) return 1;
+            *out = &dp;
+        } else {
+            *out = &it->second;
+        }
+        return 0;
+    };
+
     // buffers that later launches grow are sized up front: a reallocation in the middle of the
     // multi-stream phase would free memory a kernel in flight still uses
     {
         uint64_t need_bnd = 0;
         size_t tail_cols = 0, tail_items = 0, launch_total = 16;
         int max_passes = 1;
-        for (uint32_t q = 0; q < qn; ++q) {
-            int per_cu = 1;
-            if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
-            DbPlan *dp = nullptr;
-            if (get_db_plan(c, main_mode, n_workgroups(c, per_cu), rotated[q] != 0, &dp)) return 1;
-            size_t nsegs = 1;
-            if (qps[q].passes > 1 && dp->have_main) {
-                uint64_t cols = dp->main.bnd_cols;
-                if (c->opt_dynamic) {
-                    std::vector<std::pair<uint32_t, uint32_t>> segs;
-                    boundary_segments(c, dp->main, segs, &cols);
-                    nsegs = segs.size();
+        for (size_t ri = 0; ri < ranges.size(); ++ri)
+            for (uint32_t q = 0; q < qn; ++q) {
+                DbPlan *dp = nullptr;
+                if (plan_of(ri, q, &dp)) return 1;
+                size_t nsegs = 1;
+                if (qps[q].passes > 1 && dp->have_main) {
+                    uint64_t cols = dp->main.bnd_cols;
+                    if (c->opt_dynamic) {
+                        std::vector<std::pair<uint32_t, uint32_t>> segs;
+                        boundary_segments(c, dp->main, segs, &cols);
+                        nsegs = segs.size();
+                    }
+                    need_bnd = std::max<uint64_t>(need_bnd, cols * 64);
                 }
-                need_bnd = std::max<uint64_t>(need_bnd, cols * 64);
+                launch_total += (size_t)qps[q].passes * std::max<size_t>(nsegs, 2);   // two kernels per pass when the list is split over two streams
+                tail_cols = std::max<size_t>(tail_cols, dp->tail.cols);
+                tail_items = std::max<size_t>(tail_items, dp->tail.n);
+                max_passes = std::max(max_passes, (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
             }
-            launch_total += (size_t)qps[q].passes * std::max<size_t>(nsegs, 2);   // two kernels per pass when the list is split over two streams
-            tail_cols = std::max<size_t>(tail_cols, dp->tail.cols);
-            tail_items = std::max<size_t>(tail_items, dp->tail.n);
-            max_passes = std::max(max_passes, (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
-        }
         HIP_TRY(c->d_bnd.reserve(need_bnd));
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
@@ -790,44 +959,53 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->ev_query.push_back(e);
     }
-    // Longest query first: its promotion re-runs (a handful of long serial chains on stream 3) then overlap
-    // the bulk kernels of the shorter queries instead of running alone at the end.
-    for (uint32_t k = 0; k < qn; ++k) {
-        const uint32_t q = qn - 1 - k;                 // queries arrive sorted by ascending length
-        int per_cu = 1;
-        if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
-        DbPlan *dp = nullptr;
-        if (get_db_plan(c, main_mode, n_workgroups(c, per_cu), rotated[q] != 0, &dp)) return 1;
-        int32_t *row = c->d_scores.p + (size_t)q * S;
-        if (getenv("SWIMM_HIP_DEBUG"))
-            fprintf(stderr, "swimm_hip: query %u: %d workgroups (%d per CU), %u tail items, main %s\n", q, dp->main.n_wg, per_cu, dp->tail.n, dp->have_main ? "yes" : "no");
-        // The long-sequence tail (a few long serial chains, one wave each) runs beside the bulk kernel: 3 bulk waves
-        // (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly.  One tail launch at a time: several were
-        // measured 5 % slower on c3, and the chained passes of concurrent launches could wait for each other's workgroups.
-        //
-        // A batch of short one-pass queries is different (see the plans above): each of them is bound from below by
-        // the longest sequence's serial chain (2.4 ms for 5 000 residues, longer than the query's whole bulk work on
-        // a database of 1e8 residues), wherever that sequence is aligned.  They run whole on one of three streams in
-        // rotation, so that three are in flight and each one's chain is covered by the others' work: 300 queries of
-        // 100 residues against 1e8: 3 480 -> 4 750 GCUPS, of 40 residues: 1 570 -> 3 000.  (Three streams, because HIP
-        // multiplexes streams onto four hardware queues and the fourth carries the promotion re-runs; with seven
-        // streams a tail kernel landed in the bulk stream's queue and held it back: -18 % on c3.)
-        hipStream_t tail_stream = c->stream2, bulk_stream = c->stream;
-        LaneScratch *tail_scratch = &c->tail_scratch;
-        // (with an extreme sequence in the database the short queries keep their tail kernel, but still take turns on
-        // the three streams: three 17 ms chains at a time instead of one)
-        if (rotated[q] || (many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows)) {
-            switch (one_pass_seen++ % 3) {
-            case 0: tail_stream = bulk_stream = c->stream; tail_scratch = &c->tail_scratch_a; break;
-            case 1: tail_stream = bulk_stream = c->stream_b; tail_scratch = &c->tail_scratch_b; break;
-            default: tail_stream = bulk_stream = c->stream2; break;
+    for (size_t ri = 0; ri < ranges.size(); ++ri) {
+        if (streaming) {
+            ChunkRec &ch = c->chunks[ri];
+            if (upload_chunk(c, ch)) return 1;               // returns when the host bytes are consumed; the tile kernel is still running
+            HIP_TRY(hipStreamWaitEvent(c->stream, ch.ready, 0));
+            HIP_TRY(hipStreamWaitEvent(c->stream2, ch.ready, 0));
+        }
+        // Longest query first: its promotion re-runs (a handful of long serial chains on stream 3) then overlap
+        // the bulk kernels of the shorter queries instead of running alone at the end.
+        for (uint32_t k = 0; k < qn; ++k) {
+            const uint32_t q = qn - 1 - k;                 // queries arrive sorted by ascending length
+            DbPlan *dp = nullptr;
+            if (plan_of(ri, q, &dp)) return 1;
+            int32_t *row = c->d_scores.p + (size_t)q * S;
+            if (dbg)
+                fprintf(stderr, "swimm_hip: range %zu query %u: %d workgroups, %u tail items, main %s\n", ri, q, dp->main.n_wg, dp->tail.n, dp->have_main ? "yes" : "no");
+            // The long-sequence tail (a few long serial chains, one wave each) runs beside the bulk kernel: 3 bulk waves
+            // (144 VGPRs) + 1 lane wave (80) fill a SIMD's 512 registers exactly.  One tail launch at a time: several were
+            // measured 5 % slower on c3, and the chained passes of concurrent launches could wait for each other's workgroups.
+            //
+            // A batch of short one-pass queries is different (see the plans above): each of them is bound from below by
+            // the longest sequence's serial chain (2.4 ms for 5 000 residues, longer than the query's whole bulk work on
+            // a database of 1e8 residues), wherever that sequence is aligned.  They run whole on one of three streams in
+            // rotation, so that three are in flight and each one's chain is covered by the others' work: 300 queries of
+            // 100 residues against 1e8: 3 480 -> 4 750 GCUPS, of 40 residues: 1 570 -> 3 000.  (Three streams, because HIP
+            // multiplexes streams onto four hardware queues and the fourth carries the promotion re-runs; with seven
+            // streams a tail kernel landed in the bulk stream's queue and held it back: -18 % on c3.)
+            hipStream_t tail_stream = c->stream2, bulk_stream = c->stream;
+            LaneScratch *tail_scratch = &c->tail_scratch;
+            // (with an extreme sequence in the database the short queries keep their tail kernel, but still take turns on
+            // the three streams: three 17 ms chains at a time instead of one)
+            if (rotated[q] || (many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows)) {
+                switch (one_pass_seen++ % 3) {
+                case 0: tail_stream = bulk_stream = c->stream; tail_scratch = &c->tail_scratch_a; break;
+                case 1: tail_stream = bulk_stream = c->stream_b; tail_scratch = &c->tail_scratch_b; break;
+                default: tail_stream = bulk_stream = c->stream2; break;
+                }
+            }
+            if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
+            if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row, bulk_stream, !streaming)) return 1;
+            if (ri + 1 == ranges.size()) {
+                HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
+                HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
             }
         }
-        if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
-        if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row, bulk_stream)) return 1;
-        HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
-        HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
     }
+    if (streaming && sync_lengths(c)) return 1;    // the promotion re-runs stop every alignment at its true length
     const double t_issued = now_s();
     // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
     // f16 results >= 2048 are re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; each
@@ -927,11 +1105,12 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->kernel_ms += ms;
     if (dbg)
-        fprintf(stderr, "swimm_hip: queries %u..%u: plans + buffers %.3f s, launches issued %.3f s, ladder + drain %.3f s (device %.3f s)\n", qb, qe,
-                t_sized - t_begin, t_issued - t_sized, now_s() - t_issued, ms * 1e-3);
+        fprintf(stderr, "swimm_hip: queries %u..%u%s: plans + buffers %.3f s, launches issued %.3f s, ladder + drain %.3f s (device %.3f s)\n", qb, qe,
+                streaming ? " (streaming upload)" : "", t_sized - t_begin, t_issued - t_sized, now_s() - t_issued, ms * 1e-3);
     uint32_t werr = 0;
     HIP_TRY(hipMemcpy(&werr, c->d_err.p, sizeof werr, hipMemcpyDeviceToHost));
     if (werr) return fail("pipeline watchdog expired (code %u): results discarded", werr);
+    if (streaming) { release_plans(c); c->groups_dirty = true; }   // (the cached lists of the resident database are built on the next search)
     return 0;
 }
 
@@ -981,6 +1160,7 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream_b) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreate(&c->stream_up) != hipSuccess || hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess) {
@@ -1028,6 +1208,9 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     for (hipEvent_t e : c->ev_query) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
+    if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);
+    c->up_b.release(); c->up_n.release(); c->up_disp.release(); c->up_gcols.release(); c->up_off.release(); c->up_goff.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1070,61 +1253,22 @@ int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint
             return fail("swimm_hip_add_chunk: group %u (disp %u, n %u) runs past vD=%llu", g, b_disp[g], n[g], (unsigned long long)vD);
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t per = kGroupSeqs / vl;
-    const uint32_t dev_groups = (group_count + per - 1) / per;
-    std::vector<uint64_t> goff(dev_groups);
-    std::vector<uint32_t> gcols(dev_groups);
-    uint64_t bytes = 0;
-    for (uint32_t g = 0; g < dev_groups; ++g) {
+    ChunkRec rec;
+    rec.kind = 0;
+    rec.h_b = b; rec.vD = vD; rec.h_n = n; rec.h_disp = b_disp; rec.group_count = group_count; rec.vl = vl;
+    rec.n_groups = (group_count + per - 1) / per;
+    rec.goff.resize(rec.n_groups);
+    rec.gcols.resize(rec.n_groups);
+    for (uint32_t g = 0; g < rec.n_groups; ++g) {
         uint32_t mx = 0;
         for (uint32_t v = g * per; v < std::min(group_count, (g + 1) * per); ++v) mx = std::max<uint32_t>(mx, n[v]);
         mx = std::max<uint32_t>(mx, 1);
-        gcols[g] = (mx + kChunkCols - 1) / kChunkCols * kChunkCols;
-        goff[g] = bytes;
-        bytes += (uint64_t)gcols[g] * kGroupSeqs;
+        rec.gcols[g] = (mx + kChunkCols - 1) / kChunkCols * kChunkCols;
     }
-    uint8_t *d_b = nullptr, *d_tiled = nullptr;
-    uint16_t *d_n = nullptr;
-    uint32_t *d_disp = nullptr, *d_gcols = nullptr, *d_len = nullptr;
-    uint64_t *d_goff = nullptr;
-    std::vector<uint32_t> lens((size_t)dev_groups * kGroupSeqs);
-    auto cleanup = [&]() { (void)hipFree(d_b); (void)hipFree(d_n); (void)hipFree(d_disp); (void)hipFree(d_gcols); (void)hipFree(d_goff); (void)hipFree(d_len); };
-#define TRY_OR_CLEAN(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); (void)hipFree(d_tiled); return fail("%s: %s", #expr, hipGetErrorString(e__)); } } while (0)
-    TRY_OR_CLEAN(hipMalloc((void **)&d_b, vD));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_n, group_count * sizeof(uint16_t)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_disp, group_count * sizeof(uint32_t)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_gcols, dev_groups * sizeof(uint32_t)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_goff, dev_groups * sizeof(uint64_t)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_tiled, bytes));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_len, lens.size() * sizeof(uint32_t)));
-    TRY_OR_CLEAN(hipMemsetAsync(d_len, 0, lens.size() * sizeof(uint32_t), c->stream));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_b, b, vD, hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_n, n, group_count * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_disp, b_disp, group_count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_gcols, gcols.data(), dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_goff, goff.data(), dev_groups * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(launch_retile(d_b, d_n, d_disp, group_count, vl, d_goff, d_gcols, dev_groups, d_tiled, d_len, c->stream));
-    TRY_OR_CLEAN(hipMemcpyAsync(lens.data(), d_len, lens.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
-#undef TRY_OR_CLEAN
-    cleanup();
-    ChunkRec rec;
-    rec.d_tiled = d_tiled;
     rec.first_seq = first_group * vl;
     rec.n_seq = (uint64_t)group_count * vl;
-    rec.group0 = (uint32_t)c->groups.size();
-    rec.n_groups = dev_groups;
-    for (uint32_t g = 0; g < dev_groups; ++g) {
-        GroupDesc gd;
-        gd.db = d_tiled + goff[g];
-        gd.ncols = gcols[g];
-        gd.seq0 = (uint32_t)((rec.group0 + g) * kGroupSeqs);
-        c->groups.push_back(gd);
-        c->group_col_off.push_back(c->total_cols);
-        c->total_cols += gcols[g];
-    }
-    c->seq_len.insert(c->seq_len.end(), lens.begin(), lens.end());
-    c->chunks.push_back(rec);
-    c->groups_dirty = true;
+    if (register_chunk(c, rec, {})) return 1;
+    if (!c->opt_lazy_upload && upload_chunk(c, c->chunks.back())) return 1;
     return 0;
 }
 
@@ -1133,62 +1277,28 @@ int swimm_hip_add_sequences(swimm_hip_ctx *c, const uint16_t *lengths, const cha
     if (!c || !lengths || !codes) return fail("swimm_hip_add_sequences: NULL argument");
     if (n_seq == 0) return fail("swimm_hip_add_sequences: empty slab");
     if (n_seq > 0x7FFFFFFFull) return fail("swimm_hip_add_sequences: more than 2^31 sequences in one slab");
-    std::vector<uint32_t> off(n_seq + 1);
+    ChunkRec rec;
+    rec.kind = 1;
+    rec.off.resize(n_seq + 1);
     uint64_t total = 0;
-    for (uint64_t i = 0; i < n_seq; ++i) { off[i] = (uint32_t)total; total += lengths[i]; if (total > 0xFFFFFFF0ull) return fail("swimm_hip_add_sequences: slab larger than 4 GiB"); }
-    off[n_seq] = (uint32_t)total;
+    for (uint64_t i = 0; i < n_seq; ++i) { rec.off[i] = (uint32_t)total; total += lengths[i]; if (total > 0xFFFFFFF0ull) return fail("swimm_hip_add_sequences: slab larger than 4 GiB"); }
+    rec.off[n_seq] = (uint32_t)total;
     HIP_TRY(hipSetDevice(c->device));
-    const uint32_t dev_groups = (uint32_t)((n_seq + kGroupSeqs - 1) / kGroupSeqs);
-    std::vector<uint64_t> goff(dev_groups);
-    std::vector<uint32_t> gcols(dev_groups);
-    uint64_t bytes = 0;
-    for (uint32_t g = 0; g < dev_groups; ++g) {
+    rec.h_codes = codes; rec.code_bytes = total;
+    rec.n_groups = (uint32_t)((n_seq + kGroupSeqs - 1) / kGroupSeqs);
+    rec.goff.resize(rec.n_groups);
+    rec.gcols.resize(rec.n_groups);
+    for (uint32_t g = 0; g < rec.n_groups; ++g) {
         uint32_t mx = 1;
         const uint64_t e = std::min<uint64_t>(n_seq, (uint64_t)(g + 1) * kGroupSeqs);
         for (uint64_t i = (uint64_t)g * kGroupSeqs; i < e; ++i) mx = std::max<uint32_t>(mx, lengths[i]);
-        gcols[g] = (mx + kChunkCols - 1) / kChunkCols * kChunkCols;
-        goff[g] = bytes;
-        bytes += (uint64_t)gcols[g] * kGroupSeqs;
+        rec.gcols[g] = (mx + kChunkCols - 1) / kChunkCols * kChunkCols;
     }
-    uint8_t *d_codes = nullptr, *d_tiled = nullptr;
-    uint32_t *d_off = nullptr, *d_gcols = nullptr;
-    uint64_t *d_goff = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_codes); (void)hipFree(d_off); (void)hipFree(d_gcols); (void)hipFree(d_goff); };
-#define TRY_OR_CLEAN(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); (void)hipFree(d_tiled); return fail("%s: %s", #expr, hipGetErrorString(e__)); } } while (0)
-    TRY_OR_CLEAN(hipMalloc((void **)&d_codes, std::max<uint64_t>(total, 1)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_off, off.size() * sizeof(uint32_t)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_gcols, dev_groups * sizeof(uint32_t)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_goff, dev_groups * sizeof(uint64_t)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_tiled, bytes));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_codes, codes, total, hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_gcols, gcols.data(), dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_goff, goff.data(), dev_groups * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    TRY_OR_CLEAN(launch_tile_sequences(d_codes, d_off, (uint32_t)n_seq, d_goff, d_gcols, dev_groups, d_tiled, c->stream));
-    TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
-#undef TRY_OR_CLEAN
-    cleanup();
-    ChunkRec rec;
-    rec.d_tiled = d_tiled;
     rec.first_seq = first_seq;
     rec.n_seq = n_seq;
-    rec.group0 = (uint32_t)c->groups.size();
-    rec.n_groups = dev_groups;
-    for (uint32_t g = 0; g < dev_groups; ++g) {
-        GroupDesc gd;
-        gd.db = d_tiled + goff[g];
-        gd.ncols = gcols[g];
-        gd.seq0 = (uint32_t)((rec.group0 + g) * kGroupSeqs);
-        c->groups.push_back(gd);
-        c->group_col_off.push_back(c->total_cols);
-        c->total_cols += gcols[g];
-    }
-    const size_t base = c->seq_len.size();
-    c->seq_len.resize(base + (size_t)dev_groups * kGroupSeqs, 0);
-    for (uint64_t i = 0; i < n_seq; ++i) c->seq_len[base + i] = lengths[i];
-    c->chunks.push_back(rec);
-    c->groups_dirty = true;
-    release_plans(c);
+    std::vector<uint32_t> lens(lengths, lengths + n_seq);
+    if (register_chunk(c, rec, lens)) return 1;
+    if (!c->opt_lazy_upload && upload_chunk(c, c->chunks.back())) return 1;
     return 0;
 }
 
@@ -1196,7 +1306,8 @@ int swimm_hip_clear_db(swimm_hip_ctx *c)
 {
     if (!c) return fail("swimm_hip_clear_db: NULL ctx");
     (void)hipSetDevice(c->device);
-    for (auto &ch : c->chunks) (void)hipFree(ch.d_tiled);
+    (void)hipDeviceSynchronize();                 // nothing in flight may still read the chunks
+    for (auto &ch : c->chunks) { (void)hipFree(ch.d_tiled); (void)hipFree(ch.d_len); if (ch.ready) (void)hipEventDestroy(ch.ready); }
     c->chunks.clear(); c->groups.clear(); c->group_col_off.clear(); c->seq_len.clear();
     c->total_cols = 0;
     release_plans(c);
@@ -1395,6 +1506,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         if (value < 0 || value > 2) return fail("tail_mode must be 0 (auto), 1 (all groups via the lane kernel) or 2 (none)");
         c->opt_tail_mode = value;
         release_plans(c);
+    } else if (!strcmp(key, "lazy_upload")) {
+        c->opt_lazy_upload = value != 0;
     } else if (!strcmp(key, "lane_acquire")) {
         c->opt_lane_acquire = value != 0;
     } else if (!strcmp(key, "wg_limit")) {
@@ -1450,6 +1563,8 @@ int swimm_hip_search_chunks(const char *query_sequences, const uint16_t *query_s
             swimm_hip_ctx *ctx = nullptr;
             auto bail = [&]() { errs[g] = swimm_hip_last_error(); if (ctx) swimm_hip_destroy(ctx); };
             if (swimm_hip_create(g, &ctx)) return bail();
+            // the caller's chunks outlive this call: stream them in while the search runs (X2 overlapped with compute)
+            if (swimm_hip_set_option(ctx, "lazy_upload", 1)) return bail();
             if (swimm_hip_set_queries(ctx, query_sequences, query_sequences_lengths, query_disp, query_sequences_count,
                                       submat, open_gap, extend_gap)) return bail();
             for (uint32_t ci : shard[g])

@@ -74,6 +74,7 @@ class HipSearcher:
         _check(self._L.swimm_hip_create(C.c_int(device), C.byref(self._ctx)))
         self.device = device
         self.n_queries = 0
+        self._keep = []          # host arrays a lazy upload still points at
 
     def close(self):
         if self._ctx:
@@ -112,6 +113,7 @@ class HipSearcher:
         b = np.ascontiguousarray(b, dtype=np.int8)
         n = np.ascontiguousarray(n, dtype=np.uint16)
         b_disp = np.ascontiguousarray(b_disp, dtype=np.uint32)
+        self._keep.append((b, n, b_disp))
         _check(self._L.swimm_hip_add_chunk(self._ctx, _p(b), C.c_uint64(b.size), _p(n), _p(b_disp), C.c_uint32(len(n)),
                                            C.c_uint32(vl), C.c_uint64(first_group)))
 
@@ -121,10 +123,12 @@ class HipSearcher:
         codes = np.ascontiguousarray(codes, dtype=np.int8)
         if int(lengths.astype(np.int64).sum()) != codes.size:
             raise ValueError("lengths do not add up to the number of codes")
+        self._keep.append((lengths, codes))
         _check(self._L.swimm_hip_add_sequences(self._ctx, _p(lengths), _p(codes), C.c_uint64(len(lengths)), C.c_uint64(first_seq)))
 
     def clear_db(self):
         _check(self._L.swimm_hip_clear_db(self._ctx))
+        self._keep = []
 
     def search(self, score_stride: int, out: np.ndarray | None = None):
         """-> (scores int32 [n_queries, score_stride], work_time seconds)"""
@@ -133,6 +137,7 @@ class HipSearcher:
         assert out.dtype == np.int32 and out.flags.c_contiguous and out.shape == (self.n_queries, score_stride)
         wt = C.c_double()
         _check(self._L.swimm_hip_search(self._ctx, _p(out), C.c_uint64(score_stride), C.byref(wt)))
+        self._keep = []          # everything is resident now
         return out, wt.value
 
     def search_topr(self, r: int, n_valid: int):
@@ -141,6 +146,7 @@ class HipSearcher:
         ti = np.zeros((self.n_queries, r), dtype=np.int64)
         wt = C.c_double()
         _check(self._L.swimm_hip_search_topr(self._ctx, C.c_uint32(r), C.c_uint64(n_valid), _p(ts), _p(ti), C.byref(wt)))
+        self._keep = []
         return ts, ti, wt.value
 
     def last_stats(self):

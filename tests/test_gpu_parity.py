@@ -173,3 +173,67 @@ def test_errors_are_loud():
             s.set_queries(np.zeros(4, np.int8), np.array([4], np.uint16), np.array([0, 4], np.uint32), np.zeros(768, np.int8), 100, 100)
         with pytest.raises(hip_backend.SwimmHipError):
             s.add_chunk(np.zeros(48, np.int8), np.array([1], np.uint16), np.array([0], np.uint32), 48, 0)
+
+
+@pytest.mark.parametrize("opts", [{}, {"tail_mode": 2}, {"tail_mode": 1}, {"dynamic": 0}, {"f16": 0, "bnd_mib": 1}, {"rows_per_wave": 16, "waves": 4}])
+def test_streaming_upload_same_scores(tmp_path, golden, opts):
+    """X2 overlapped with compute (MICsearch.c:85-91): with "lazy_upload" the chunks are copied and tiled while earlier
+    chunks are being aligned, each chunk with work lists of its own.  Same golden scores with uploads in flight, in the
+    reference chunk layout (6 chunks) and as .seq slabs; the second search runs on the resident copy."""
+    q, pp, chunked = golden_inputs(tmp_path, golden, vl=128, max_chunk=16000)
+    assert len(chunked["chunks"]) >= 4
+    N = golden["search"]["n_sequences"]
+    want = load_npy("scores_blosum62_g10_e2.npy")
+    with hip_backend.HipSearcher(0) as s:
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.set_option("lazy_upload", 1)
+        s.set_queries(q["a"], q["m"], q["disp"], matrix("blosum62"), 10, 2)
+        vc = load_chunks(s, chunked, 128)
+        first, _ = s.search(vc * 128)
+        st = s.last_stats()
+        again, _ = s.search(vc * 128)
+        assert np.array_equal(first[:, :N], want) and np.array_equal(again[:, :N], want)
+        assert st["promoted"] > 0
+        # .seq slabs of 128 sequences, streamed the same way
+        s.clear_db()
+        lens, codes = pp["lengths"].astype(np.uint16), pp["codes"]
+        offs = np.concatenate([[0], np.cumsum(pp["lengths"])])
+        for s0 in range(0, N, 128):
+            s1 = min(N, s0 + 128)
+            s.add_sequences(lens[s0:s1], codes[offs[s0]:offs[s1]], first_seq=s0)
+        slab, _ = s.search((N + 127) // 128 * 128)
+        ts, ti, _ = s.search_topr(10, N)
+        assert np.array_equal(slab[:, :N], want)
+        for k in range(want.shape[0]):
+            os_, oi = port.topr(want[k], 10)
+            assert np.array_equal(ts[k], os_) and np.array_equal(ti[k], oi)
+
+
+def test_streaming_upload_c2_shape():
+    """a tenth of the c2 shard in 12 chunks: streamed search == search of the resident copy == eager upload, and the
+    whole-call drop-in (always streaming) agrees"""
+    import bench
+    from swimm_amd import host, submat
+    shard = bench.build_shard(2, 0.1)
+    chunks = host.Chunks(shard["lengths"], shard["codes"], 128, 5 << 20)
+    assert len(chunks.chunks) >= 10
+    qa = shard["query"]
+    m, disp, sm = np.array([len(qa)], np.uint16), np.array([0, len(qa)], np.uint32), submat.table("blosum62")
+    res = {}
+    for lazy in (0, 1):
+        with hip_backend.HipSearcher(0) as s:
+            s.set_option("lazy_upload", lazy)
+            s.set_queries(qa, m, disp, sm, 10, 2)
+            for ch in chunks.chunks:
+                s.add_chunk(ch["b"], ch["n"], ch["disp"], 128, ch["first_group"])
+            res[lazy], _ = s.search(chunks.vc * 128)
+            if lazy:
+                res["again"], _ = s.search(chunks.vc * 128)
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res["again"])
+    allsc, _ = hip_backend.search_chunks(qa, m, disp, chunks.vc, chunks.chunks, sm, 10, 2, 1, 128)
+    assert np.array_equal(allsc, res[0])
+    offs = np.concatenate([[0], np.cumsum(shard["lengths"].astype(np.int64))])
+    for i in list(np.random.default_rng(3).integers(0, shard["n"], 60)) + [int(np.argmax(res[0][0, :shard["n"]]))]:
+        assert res[0][0, i] == port.pair_score(qa, shard["codes"][offs[i]:offs[i + 1]], sm, 10, 2), i
+    chunks.close()

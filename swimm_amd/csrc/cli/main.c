@@ -167,11 +167,12 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
 }
 
 /* Mode 2 (the reference's het_search_*, HETsearch.c:57,96-104: host and devices pull chunks from one queue): here
- * the split is fixed before the search, because the GPUs keep their share resident and search it in one go.  The
- * host's rate is measured on a sample of the shortest sequences, the GPUs' is taken as SWIMM_HYBRID_GPU_GCUPS (default
- * 7500 per device, plus start-up and upload time); the host gets the shortest sequences it can finish in the time
- * the GPUs need for the rest.  Returns the number of sequences for the host (0: not worth it). */
-static uint64_t hybrid_split(const swimm_options *o, const swimm_queries *q, const char *submat, const swimm_db *db, int G)
+ * the split is fixed before the search, because the GPUs keep their share resident and search it in one go.  Both
+ * rates are MEASURED before the clock starts: the host's on a sample of the shortest sequences with the shortest
+ * query, the GPU's by a probe search of the real query batch against a sample from the long end of the database
+ * on device 0 (context creation and upload are timed too).  The host gets the shortest sequences it can finish in
+ * the time the GPUs need for the rest.  Returns the number of sequences for the host (0: not worth it). */
+static uint64_t hybrid_split(const swimm_hip_api *api, const swimm_options *o, const swimm_queries *q, const char *submat, const swimm_db *db, int G)
 {
     const uint64_t vl = (uint64_t)o->vector_length;
     const char *forced = getenv("SWIMM_HYBRID_CPU_SEQUENCES");   /* test hook: fixed host share */
@@ -191,19 +192,58 @@ static uint64_t hybrid_split(const swimm_options *o, const swimm_queries *q, con
     swimm_single_chunk sc;
     int rc = swimm_assemble_single_chunk(db->lengths, db->codes, sample, o->vector_length, o->cpu_block_size, &sc);
     if (rc) die_host(rc);
+    cpu_leg(o, &q0, submat, &sc, sample, 1, s1, i1, &st);      /* wakes the thread team */
+    st.seconds = 0;
     cpu_leg(o, &q0, submat, &sc, sample, 1, s1, i1, &st);
     swimm_single_chunk_free(&sc);
     sample_res = 0;
     for (uint64_t i = 0; i < sample; ++i) sample_res += db->lengths[i];
     const double host_rate = (double)sample_res * q->m[0] / (st.seconds > 1e-6 ? st.seconds : 1e-6);   /* cells per second */
-    const char *env = getenv("SWIMM_HYBRID_GPU_GCUPS");
-    const double gpu_rate = (env && atof(env) > 0 ? atof(env) : 7500.0) * 1e9 * G;
-    const double fixed = 0.10 + (double)db->residues / G / 15e9;   /* context creation + pageable upload, measured 0.03 s + 17 GB/s */
+
+    /* GPU probe: the last sequences of the sorted database (the GPUs' end), at most 64 MB of residues */
+    uint64_t pn = 0, pres = 0;
+    while (pn < db->count - sample && pres < (64ull << 20)) pres += db->lengths[db->count - 1 - pn++];
+    pn = pn / 128 * 128;
+    if (pn == 0) return 0;
+    pres = 0;
+    for (uint64_t i = db->count - pn; i < db->count; ++i) pres += db->lengths[i];
     const double Qrows = (double)q->Q;
-    /* host_cells / host_rate = fixed + (total - host_cells) / gpu_rate */
+    double t_ctx = 0, t_up = 0, t_search = 0, t_first = 0;
+    {
+        swimm_hip_ctx *ctx = NULL;
+        const double t0 = swimm_wtime();
+        int bad = api->create(0, &ctx);
+        t_ctx = swimm_wtime() - t0;
+        if (!bad) bad = api->set_queries(ctx, q->a, q->m, q->disp, (uint32_t)q->count, submat, o->open_gap, o->extend_gap);
+        const double t1 = swimm_wtime();
+        if (!bad) bad = api->add_sequences(ctx, db->lengths + (db->count - pn), db->codes + (db->residues - pres), pn, 0);
+        t_up = swimm_wtime() - t1;
+        int32_t *ps = (int32_t *)malloc(q->count * sizeof(int32_t));
+        int64_t *pi = (int64_t *)malloc(q->count * sizeof(int64_t));
+        if (!bad) bad = api->search_topr(ctx, 1, pn, ps, pi, NULL);          /* builds the work lists, warms the code objects */
+        const double t2 = swimm_wtime();
+        t_first = t2 - (t1 + t_up);
+        if (!bad) bad = api->search_topr(ctx, 1, pn, ps, pi, NULL);
+        t_search = swimm_wtime() - t2;
+        free(ps); free(pi);
+        if (bad) { printf("SWIMM: GPU probe failed: %s\n", api->last_error()); exit(5); }
+        api->destroy(ctx);
+    }
+    const double gpu_rate = Qrows * (double)pres / (t_search > 1e-6 ? t_search : 1e-6) * G;     /* cells per second, all devices */
+    const double up_rate = (double)pres / (t_up > 1e-6 ? t_up : 1e-6);                            /* bytes per second per device */
+    /* the GPUs' time for x cells: context + the longer of upload and search (slabs stream in while the search runs) */
     const double total = Qrows * (double)db->residues;
+    const double t_upload = (double)db->residues / G / up_rate;
+    /* what a first search costs beyond the alignment itself (work lists, buffers), per database byte */
+    const double t_setup = (t_first > t_search ? t_first - t_search : 0.0) / (double)pres * (double)db->residues / G;
+    const double fixed = t_ctx + t_setup;
+    /* host_cells / host_rate = fixed + max(t_upload, (total - host_cells) / gpu_rate) */
     double host_cells = (fixed + total / gpu_rate) / (1.0 / host_rate + 1.0 / gpu_rate);
+    if ((total - host_cells) / gpu_rate < t_upload) host_cells = (fixed + t_upload) * host_rate;
     if (host_cells > 0.5 * total) host_cells = 0.5 * total;
+    if (getenv("SWIMM_DEBUG"))
+        fprintf(stderr, "swimm: hybrid probe: host %.2f GCUPS; GPU context %.3f s, setup %.3f s, upload %.1f GB/s, search %.1f GCUPS per device -> host share %.3g of %.3g cells\n",
+                host_rate / 1e9, t_ctx, t_setup, up_rate / 1e9, gpu_rate / G / 1e9, host_cells, total);
     uint64_t n = 0, res = 0;
     while (n < db->count && (double)(res + db->lengths[n]) * Qrows <= host_cells) res += db->lengths[n++];
     n = n / 128 * 128;                               /* the GPU part keeps whole lane groups */
@@ -262,7 +302,7 @@ int main(int argc, char **argv)
         if (avail <= 0) { printf("SWIMM: no MI355X visible: %s\n", api.last_error()); exit(5); }
         if (o.num_gpus > avail) { printf("SWIMM: %d GPUs requested, %d visible.\n", o.num_gpus, avail); exit(5); }
         const int G = o.num_gpus;
-        if (o.execution_mode == MODE_HYBRID) n_cpu = hybrid_split(&o, &q, submat, &db, G);
+        if (o.execution_mode == MODE_HYBRID) n_cpu = hybrid_split(&api, &o, &q, submat, &db, G);
         const uint64_t n_gpu = db.count - n_cpu;
         uint64_t cpu_residues = 0;
         for (uint64_t i = 0; i < n_cpu; ++i) cpu_residues += db.lengths[i];
@@ -328,7 +368,7 @@ int main(int argc, char **argv)
         printf("Kernel time:\t\t\t%lf seconds\n", gst.kernel_ms / 1000.0);
         printf("Promoted to int32:\t\t%ld alignments\n", (long)gst.promoted);
         if (o.execution_mode == MODE_HYBRID)   /* the reference prints "%d chunks in CPU and %d in MICs" (HETsearch.c:337-342) */
-            printf("Host CPU share:\t\t\t%ld sequences (%.2lf seconds), MI355X %ld sequences (%.2lf seconds)\n", (long)n_cpu, cst.seconds,
+            printf("Host CPU share:\t\t\t%ld sequences (%.3lf seconds), MI355X %ld sequences (%.3lf seconds)\n", (long)n_cpu, cst.seconds,
                    (long)(db.count - n_cpu), gst.seconds);
     }
     for (uint64_t i = 0; i < q.count * top; ++i) free(titles[i]);

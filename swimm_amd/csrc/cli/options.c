@@ -81,7 +81,11 @@ static int parse_opt(int key, char *arg, struct argp_state *state)
             argp_failure(state, 1, 0, "%s is not a valid option for profile technique.", arg);
         o->profile = arg[0];
         break;
-    case 'u': o->query_length_threshold = atoi(arg); break;
+    case 'u':
+        o->query_length_threshold = atoi(arg);
+        if (o->query_length_threshold < 0 || o->query_length_threshold > 65535)      /* arguments.c:119-121 */
+            argp_failure(state, 1, 0, "%s is not a valid option for query length threshold.", arg);
+        break;
     case 'v':
         o->vector_length = atoi(arg);
         if (o->vector_length != 16 && o->vector_length != 32)

@@ -41,7 +41,10 @@ struct PipeParams {
     uint32_t prof_stride;       // rows allocated per code (>= passes * W * T)
     uint32_t r0;                // first query row of this pass
     uint2 *bnd;                 // pass boundary rows (H,F per column per lane), updated in place
-    int first_pass, last_pass;
+    int first_pass, last_pass;  // one pass per launch
+    uint32_t passes;            // > 1: group-resident passes -- every workgroup takes a group through all `passes` passes back to
+                                // back (dynamic queue only); bnd then holds bnd_wg_cols columns per workgroup, touched by it alone
+    uint32_t bnd_wg_cols;
     int32_t *out;               // packed mode: score row of this query; int32 mode: out32
     int goe, ge;                // open+extend, extend
     uint32_t *err;              // watchdog word shared with the lane kernel
@@ -91,7 +94,7 @@ bool pipe_has_variant(Mode mode, int rows_per_wave);
 // registers / occupancy of one instantiation (for the host-side launch plan)
 hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, int *num_regs);
 // mangled symbol of the instantiation (nullptr when there is none)
-const char *pipe_kernel_symbol(Mode mode, int rows_per_wave, bool dynamic);
+const char *pipe_kernel_symbol(Mode mode, int rows_per_wave, bool dynamic, bool resident);
 hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, int n_wg, const PipeParams &p, hipStream_t s);
 
 // Re-tile one reference-layout chunk (sequences.c:506-526 byte interleave) into device groups.

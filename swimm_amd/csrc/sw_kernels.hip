@@ -192,7 +192,15 @@ __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *q) { return
 //      queue keeps all workgroups busy to the end.
 // The waves of a workgroup hand chunks over through an LDS ring with one workgroup barrier per chunk.  (Counters
 // between neighbouring waves instead of the barrier were tried and lost 1.5 %, see DESIGN.md.)
-template <int T, int M, bool DYN>
+// RES: group-resident passes.  A query longer than W*T rows needs several passes over every group; with RES the
+//      workgroup takes a group through ALL its passes back to back, as one continuous stream of item-passes, before it
+//      moves on: the strip boundary of a pass (the last wave's bottom row per column) goes to a scratch area that only
+//      this workgroup touches and comes back, to wave 0, one group length later -- while it is still cached -- and no
+//      pass waits for the slowest workgroup of the one before it (no launch boundary).  Every wave re-stages the
+//      profile rows of its own strip when the pass changes, so the pipeline never drains.  A group shorter than the
+//      pipeline (fewer chunks than waves) idles to the pipeline's depth between two of its passes: wave 0 must not
+//      start pass p+1 of a column before the last wave has finished pass p of it.
+template <int T, int M, bool DYN, bool RES>
 __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
 {
     static_assert(T % 4 == 0 && T >= 8, "strips are multiples of 4 rows");
@@ -214,7 +222,8 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     int *total_lds = (int *)(seq + kSeqRing);                          // chunks in the workgroup's whole sequence, once known
 
     // stage this pass's window of the query profile: rows [r0, r0 + W*T) of all 25 codes, strip k at LDS row k*TP
-    {
+    // (group-resident passes: every wave stages its own strip, pass by pass, below)
+    if (!RES) {
         const int dw_per_code = RW >> 1;
         for (int idx = threadIdx.x; idx < kCodes * dw_per_code; idx += blockDim.x) {
             const int d = idx / dw_per_code, x = idx - d * dw_per_code;
@@ -273,6 +282,9 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
 
     uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, out_slot = 0, n = 0, next_it = kNoItem;
+    uint32_t pass = 0, len = 0;            // RES: pass of the current item; steps the item-pass occupies (>= nch)
+    int staged_pass = -1;                  // RES: which pass's rows this wave's strip of the LDS profile holds
+    const uint32_t passes = RES ? p.passes : 1u;
     uint64_t bnd_off = 0;
     const uint8_t *dbp = nullptr;
     uint32_t nwa = 0, nwb = 0;     // residues of the wave's next chunk, loaded one step ahead
@@ -299,16 +311,35 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
         const int c = s - k;                      // chunk index of this wave in the workgroup's sequence
         STAMP(tA);
         if (c >= 0 && it != kNoItem) {            // wave-uniform
-            if (cc == 0) {                        // first chunk of a new item: reset the DP state
+            if (cc == 0) {                        // first chunk of a new item (RES: item-pass): reset the DP state
                 // the item is the same for the whole wave: one scalar load, descriptor in scalar registers
                 const Item iv = load_item(p.items, __builtin_amdgcn_readfirstlane(it));
                 nch = iv.ncols / C; dbp = iv.db; seq0 = iv.seq0;
                 half = iv.half; out_slot = iv.out_slot;
-                bnd_off = iv.bnd_off;
+                bnd_off = RES ? (uint64_t)blockIdx.x * p.bnd_wg_cols : iv.bnd_off;
+                len = (RES && pass + 1 < passes && nch < (uint32_t)W) ? (uint32_t)W : nch;
                 best = Ops::zero(); diag_top = Ops::zero();
 #pragma unroll
                 for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+                if (RES && staged_pass != (int)pass) {
+                    // this wave's strip of the profile for this pass: rows pass*W*T + k*T .. + T of all 25 codes.  Only
+                    // this wave reads that part of the LDS profile, so nobody has to be waited for.
+                    const uint32_t row0 = pass * (uint32_t)(W * T) + (uint32_t)(k * T);
+                    for (int idx = lane; idx < kCodes * (T / 2); idx += 64) {
+                        const int d = idx / (T / 2), x = idx - d * (T / 2);
+                        uint32_t v = *(const uint32_t *)(p.prof + (size_t)d * p.prof_stride + row0 + 2 * x);
+                        if (M == 2) {
+                            const v2s sv = as_v2s(v);
+                            v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)sv.x, (_Float16)(float)sv.y});
+                        }
+                        *(uint32_t *)(prof_lds + d * PS + (k * TP + 2 * x) * 2) = v;
+                    }
+                    staged_pass = (int)pass;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
+            if (!RES || cc < nch) {               // (RES: a short group idles here to the pipeline's depth between two passes)
             // database residues of this chunk: 4 columns of the lane's sequence(s).  They were requested one
             // step ago (below): right after the barrier every wave would otherwise stall on this global load
             // before it can form its first LDS address, with nothing else on the SIMD to cover it.
@@ -328,7 +359,9 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 const uint8_t *ndb = dbp;
                 uint32_t ncc = cc + 1, nhalf = half;
                 have_next = true;
-                if (ncc == nch) {
+                if (RES && ncc == nch && pass + 1 < passes) {
+                    ncc = 0;                       // the same group again, next pass
+                } else if (ncc == nch) {
                     // which item follows?  static: the next of the range; dynamic: the id wave 0 published in seq[]
                     if (DYN) {
                         next_it = __builtin_amdgcn_readfirstlane(seq[(n + 1) & (kSeqRing - 1)]);
@@ -354,13 +387,25 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             }
             // top boundary of the strip for these columns: H of the row above, F entering row 0
             uint2 bin[C];
+            const bool first_pass = RES ? pass == 0 : (bool)p.first_pass, last_pass = RES ? pass + 1 == passes : (bool)p.last_pass;
             if (k == 0) {
-                if (p.first_pass) {
+                if (first_pass) {
 #pragma unroll
                     for (int jj = 0; jj < C; ++jj) bin[jj] = make_uint2(0u, 0u);
                 } else {
+                    if (RES) {
+                        // written by this workgroup's last wave one group length ago: the step barriers order the two,
+                        // and the load goes to L2 (sc1), past whatever this CU's L1 still holds of the previous pass
 #pragma unroll
-                    for (int jj = 0; jj < C; ++jj) bin[jj] = p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane];
+                        for (int jj = 0; jj < C; ++jj) {
+                            const unsigned long long v = __hip_atomic_load((const unsigned long long *)(p.bnd + (bnd_off + (uint64_t)cc * C + jj) * 64 + lane),
+                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            bin[jj] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+                        }
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < C; ++jj) bin[jj] = p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane];
+                    }
                 }
             } else {
                 const uint2 *src = ring + (size_t)(((k - 1) * 2 + (c & 1)) * C) * 64 + lane;
@@ -433,13 +478,15 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 // bottom boundary of this column: to the next wave through LDS, or (last wave, more passes) to HBM
                 const uint2 bout = make_uint2(Ops::bits(H[T - 1]), Ops::bits(F));
                 if (k < W - 1) ring[(size_t)((k * 2 + (c & 1)) * C + jj) * 64 + lane] = bout;
-                else if (!p.last_pass) p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = bout;
+                else if (!last_pass) p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = bout;
                 // keep one column's lookups in flight at a time: without this fence the scheduler hoists
                 // all four columns' LDS reads and the kernel needs ~230 VGPRs (spills at 3 waves/SIMD)
                 __builtin_amdgcn_sched_barrier(0);
             }
             STAMP(tC);
-            if (++cc == nch) {   // item finished: every strip contributes its best (CPUsearch.c:670-676)
+            }   // active step
+            const bool scored = !RES ? cc + 1 == nch : cc + 1 == nch;
+            if (scored) {   // item(-pass) finished: every strip contributes its best (CPUsearch.c:670-676)
                 if (M == 2) {
                     const v2h b2 = __builtin_bit_cast(v2h, Ops::bits(best));
                     atomicMax(p.out + seq0 + lane, (int)(float)b2.x);
@@ -451,10 +498,17 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 } else {
                     atomicMax(p.out + (size_t)out_slot * 64 + lane, (int)Ops::bits(best));
                 }
+            }
+            if (++cc >= len) {
                 cc = 0;
-                ++n;
-                it = next_it;
-                pull = true;
+                if (RES && pass + 1 < passes) {
+                    ++pass;                       // same group, next pass
+                } else {
+                    pass = 0;
+                    ++n;
+                    it = next_it;
+                    pull = true;
+                }
             }
 #ifdef SWIMM_STAMPS
             STAMP(tD);
@@ -486,27 +540,27 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 #endif
 }
 
-template <int T, int M, bool DYN>
+template <int T, int M, bool DYN, bool RES>
 static hipError_t launch_one(int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
     const size_t lds = pipe_lds_bytes(T, W);
-    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, M, DYN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, M, DYN, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sw_pipe_kernel<T, M, DYN>), dim3(n_wg), dim3(W * 64), lds, s, p);
+    hipLaunchKernelGGL((sw_pipe_kernel<T, M, DYN, RES>), dim3(n_wg), dim3(W * 64), lds, s, p);
     return hipGetLastError();
 }
 
-template <int T, bool DYN>
+template <int T, bool DYN, bool RES>
 static hipError_t launch_mode(Mode mode, int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
-    if (mode == Mode::PK16) return launch_one<T, 0, DYN>(W, n_wg, p, s);
-    if (mode == Mode::I32) return launch_one<T, 1, DYN>(W, n_wg, p, s);
-    return launch_one<T, 2, DYN>(W, n_wg, p, s);
+    if (mode == Mode::PK16) return launch_one<T, 0, DYN, RES>(W, n_wg, p, s);
+    if (mode == Mode::I32) return launch_one<T, 1, DYN, RES>(W, n_wg, p, s);
+    return launch_one<T, 2, DYN, RES>(W, n_wg, p, s);
 }
 
 // Instantiations: T = 16 / 24 / 32 for every tier; the f16 tier (the default path) also has every other multiple
 // of 4 from 8 to 36, so that the launch plan can give a query W = 4, 8, 12 or 16 waves (an equal number on each of
-// the CU's 4 SIMDs) with at most 3 padding rows per wave.
+// the CU's 4 SIMDs) with at most 3 padding rows per wave.  Group-resident passes exist for the dynamic queue only.
 #define SWIMM_EXTRA_T(X) X(8) X(12) X(20) X(28) X(36)
 bool pipe_has_variant(Mode mode, int T)
 {
@@ -518,45 +572,43 @@ bool pipe_has_variant(Mode mode, int T)
     return false;
 }
 
+template <bool DYN, bool RES>
+static hipError_t launch_any(Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t s)
+{
+    if (T == 32) return launch_mode<32, DYN, RES>(mode, W, n_wg, p, s);
+    if (T == 24) return launch_mode<24, DYN, RES>(mode, W, n_wg, p, s);
+    if (T == 16) return launch_mode<16, DYN, RES>(mode, W, n_wg, p, s);
+#define X(t) if (T == t) return launch_one<t, 2, DYN, RES>(W, n_wg, p, s);
+    SWIMM_EXTRA_T(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_pipe(Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
     if (W < 1 || W > kMaxWaves || n_wg < 1 || !pipe_has_variant(mode, T)) return hipErrorInvalidValue;
     if (T > 28 && W > 12) return hipErrorInvalidValue;    // __launch_bounds__ of those instantiations
     const bool dyn = p.queue != nullptr;
-    if (dyn) {
-        if (T == 32) return launch_mode<32, true>(mode, W, n_wg, p, s);
-        if (T == 24) return launch_mode<24, true>(mode, W, n_wg, p, s);
-        if (T == 16) return launch_mode<16, true>(mode, W, n_wg, p, s);
-#define X(t) if (T == t) return launch_one<t, 2, true>(W, n_wg, p, s);
-        SWIMM_EXTRA_T(X)
-#undef X
-    } else {
-        if (T == 32) return launch_mode<32, false>(mode, W, n_wg, p, s);
-        if (T == 24) return launch_mode<24, false>(mode, W, n_wg, p, s);
-        if (T == 16) return launch_mode<16, false>(mode, W, n_wg, p, s);
-#define X(t) if (T == t) return launch_one<t, 2, false>(W, n_wg, p, s);
-        SWIMM_EXTRA_T(X)
-#undef X
-    }
-    return hipErrorInvalidValue;
+    if (p.passes > 1) return dyn ? launch_any<true, true>(mode, T, W, n_wg, p, s) : hipErrorInvalidValue;
+    return dyn ? launch_any<true, false>(mode, T, W, n_wg, p, s) : launch_any<false, false>(mode, T, W, n_wg, p, s);
 }
 
-template <int T, bool DYN>
+template <int T, bool DYN, bool RES>
 static const void *kernel_ptr(Mode mode)
 {
-    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0, DYN>;
-    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1, DYN>;
-    return (const void *)sw_pipe_kernel<T, 2, DYN>;
+    if (mode == Mode::PK16) return (const void *)sw_pipe_kernel<T, 0, DYN, RES>;
+    if (mode == Mode::I32) return (const void *)sw_pipe_kernel<T, 1, DYN, RES>;
+    return (const void *)sw_pipe_kernel<T, 2, DYN, RES>;
 }
 
-template <bool DYN>
+template <bool DYN, bool RES>
 static const void *kernel_ptr_t(Mode mode, int T)
 {
     if (!pipe_has_variant(mode, T)) return nullptr;
-    if (T == 32) return kernel_ptr<32, DYN>(mode);
-    if (T == 24) return kernel_ptr<24, DYN>(mode);
-    if (T == 16) return kernel_ptr<16, DYN>(mode);
-#define X(t) if (T == t) return (const void *)sw_pipe_kernel<t, 2, DYN>;
+    if (T == 32) return kernel_ptr<32, DYN, RES>(mode);
+    if (T == 24) return kernel_ptr<24, DYN, RES>(mode);
+    if (T == 16) return kernel_ptr<16, DYN, RES>(mode);
+#define X(t) if (T == t) return (const void *)sw_pipe_kernel<t, 2, DYN, RES>;
     SWIMM_EXTRA_T(X)
 #undef X
     return nullptr;
@@ -565,17 +617,20 @@ static const void *kernel_ptr_t(Mode mode, int T)
 hipError_t pipe_kernel_attributes(Mode mode, int T, int *num_regs)
 {
     hipFuncAttributes a;
-    const void *f = kernel_ptr_t<true>(mode, T);
+    const void *f = kernel_ptr_t<true, false>(mode, T);
     if (!f) return hipErrorInvalidValue;
     hipError_t e = hipFuncGetAttributes(&a, f);
     if (e == hipSuccess) *num_regs = a.numRegs;
+    // the group-resident variant must fit the same occupancy: report the larger of the two
+    hipFuncAttributes b;
+    if (e == hipSuccess && hipFuncGetAttributes(&b, kernel_ptr_t<true, true>(mode, T)) == hipSuccess) *num_regs = a.numRegs > b.numRegs ? a.numRegs : b.numRegs;
     return e;
 }
 
 // the code object's own (mangled) name of the instantiation a launch plan uses: what rocprofv3 lists, demangled
-const char *pipe_kernel_symbol(Mode mode, int T, bool dynamic)
+const char *pipe_kernel_symbol(Mode mode, int T, bool dynamic, bool resident)
 {
-    const void *f = dynamic ? kernel_ptr_t<true>(mode, T) : kernel_ptr_t<false>(mode, T);
+    const void *f = resident ? kernel_ptr_t<true, true>(mode, T) : dynamic ? kernel_ptr_t<true, false>(mode, T) : kernel_ptr_t<false, false>(mode, T);
     return f ? hipKernelNameRefByPtr(f, nullptr) : nullptr;
 }
 

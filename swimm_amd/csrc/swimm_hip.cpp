@@ -125,7 +125,7 @@ struct ChunkRec {
     hipEvent_t ready = nullptr; // recorded on the upload stream behind the chunk's (re-)tile kernel
 };
 
-struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true; };
+struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true, resident = false; };
 
 }  // namespace
 
@@ -153,6 +153,7 @@ struct swimm_hip_ctx {
     int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
     int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
     int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
+    int opt_resident = 1;               // 1: a multi-pass query runs as ONE launch whose workgroups take every group through all its passes back to back
     int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
     int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
     int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
@@ -544,9 +545,37 @@ static bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &p
     return c->opt_dynamic && c->opt_split && qp.passes > 2 && n_segs == 1 && pl.n_wg >= 2 && pl.split_n[1] >= (uint32_t)pl.n_wg;
 }
 
+// Group-resident passes (sw_pipe_kernel<.., RES = true>): one launch per multi-pass query, no launch boundary between passes
+// and no boundary rows shared between workgroups.
+static bool use_resident(const swimm_hip_ctx *c, const QueryPlan &qp) { return c->opt_dynamic && c->opt_resident && qp.passes > 1; }
+// boundary scratch of that mode: per workgroup, the columns of the longest group of the list (64 lanes x 8 B each)
+static uint64_t resident_bnd_elems(const Plan &pl) { return pl.n_items ? (uint64_t)pl.n_wg * pl.queue_cols[0] * 64 : 0; }
+
 // `st`: stream of the one-kernel-per-pass path (one-pass queries rotate over three streams)
 int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st, bool allow_split)
 {
+    if (use_resident(c, qp)) {
+        PipeParams p{};
+        fill_common(c, qp, p);
+        if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
+        if (c->d_bnd.cap < resident_bnd_elems(pl)) return fail("internal: boundary scratch too small");
+        p.items = pl.queue_items.p;
+        p.n_items = pl.n_items;
+        const int n_wg = (int)std::min<uint32_t>((uint32_t)pl.n_wg, pl.n_items);
+        // every item-pass takes its chunks, or the pipeline's depth if it is shorter than that
+        p.max_steps = (uint32_t)std::min<uint64_t>((pl.total_chunks + (uint64_t)pl.n_items * kMaxWaves) * qp.passes + kMaxWaves + 1, 0x3ffffff0u);
+        p.queue = c->d_queue.p + c->queue_next++;
+        p.passes = (uint32_t)qp.passes;
+        p.bnd_wg_cols = pl.queue_cols[0];
+        p.r0 = 0;
+        p.first_pass = 1; p.last_pass = 0;
+        p.out = out_row;
+        p.err = c->d_err.p;
+        HIP_TRY(launch_pipe(mode, qp.T, qp.W, n_wg, p, st));
+        c->launches++;
+        c->cells += pl.total_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * qp.passes * (mode == Mode::I32 ? 64 : 128);
+        return 0;
+    }
     std::vector<std::pair<uint32_t, uint32_t>> segs;
     uint64_t seg_cols = pl.bnd_cols;
     if (c->opt_dynamic && qp.passes > 1) boundary_segments(c, pl, segs, &seg_cols);
@@ -750,6 +779,7 @@ int upload_chunk(swimm_hip_ctx *c, ChunkRec &r)
     if (r.uploaded) return 0;
     hipStream_t s = c->stream_up;
     const uint32_t dev_groups = r.n_groups;
+    const double t_up0 = now_s();
     HIP_TRY(c->up_gcols.reserve(dev_groups));
     HIP_TRY(c->up_goff.reserve(dev_groups));
     HIP_TRY(hipMemcpyAsync(c->up_gcols.p, r.gcols.data(), dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -774,6 +804,10 @@ int upload_chunk(swimm_hip_ctx *c, ChunkRec &r)
     }
     HIP_TRY(hipEventRecord(r.ready, s));
     HIP_TRY(hipEventSynchronize(c->ev_copied));      // the caller's buffers have been read
+    if (getenv("SWIMM_HIP_DEBUG")) {
+        const uint64_t bytes = r.kind == 0 ? r.vD : r.code_bytes;
+        fprintf(stderr, "swimm_hip: chunk of %.1f MB copied in %.2f ms (%.1f GB/s)\n", bytes / 1e6, (now_s() - t_up0) * 1e3, bytes / 1e9 / (now_s() - t_up0));
+    }
     r.uploaded = true;
     r.h_b = nullptr; r.h_n = nullptr; r.h_disp = nullptr; r.h_codes = nullptr;
     std::vector<uint32_t>().swap(r.off);
@@ -887,7 +921,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         }
     }
     c->last_plans.resize(c->qm.size());
-    for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; c->last_plans[qb + q] = qps[q]; }
+    for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = use_resident(c, qps[q]); c->last_plans[qb + q] = qps[q]; }
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
@@ -921,7 +955,9 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 DbPlan *dp = nullptr;
                 if (plan_of(ri, q, &dp)) return 1;
                 size_t nsegs = 1;
-                if (qps[q].passes > 1 && dp->have_main) {
+                if (use_resident(c, qps[q]) && dp->have_main) {
+                    need_bnd = std::max<uint64_t>(need_bnd, resident_bnd_elems(dp->main));
+                } else if (qps[q].passes > 1 && dp->have_main) {
                     uint64_t cols = dp->main.bnd_cols;
                     if (c->opt_dynamic) {
                         std::vector<std::pair<uint32_t, uint32_t>> segs;
@@ -1461,7 +1497,7 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *c, uint32_t q, char *buf, size_t b
     if (!c || !buf || buf_len == 0) return fail("swimm_hip_last_kernel_name: NULL argument");
     if (q >= c->last_plans.size()) return fail("swimm_hip_last_kernel_name: query %u was not part of the last search", q);
     const QueryPlan &qp = c->last_plans[q];
-    const char *sym = pipe_kernel_symbol(qp.mode, qp.T, qp.dynamic);
+    const char *sym = pipe_kernel_symbol(qp.mode, qp.T, qp.dynamic, qp.resident);
     if (!sym) return fail("swimm_hip_last_kernel_name: no kernel for rows_per_wave=%d", qp.T);
     int status = 0;
     char *dem = abi::__cxa_demangle(sym, nullptr, nullptr, &status);
@@ -1496,6 +1532,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "lane_rows")) {
         c->opt_lane_rows = value != 0;
+    } else if (!strcmp(key, "resident")) {
+        c->opt_resident = value != 0;
     } else if (!strcmp(key, "split")) {
         c->opt_split = value != 0;
     } else if (!strcmp(key, "dynamic")) {

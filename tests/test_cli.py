@@ -151,3 +151,41 @@ def test_search_over_several_devices(dbprefix, golden, mode):
     assert "(3 GPUs)" in p.stdout or "and 3 GPUs)" in p.stdout
     p = subprocess.run([SWIMM, "-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-x", "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     assert p.returncode == 5 and "4 GPUs requested, 3 visible" in p.stdout
+
+
+@pytest.mark.gpu
+def test_profile_flags_accepted_same_listing(dbprefix, golden):
+    """-p Q|S|A and -u (arguments.c:109-121, swimm.c:81-85): the flags of the reference's profile choice are part of
+    the command line; on the GPU there is one lookup scheme (DESIGN.md section 6b.4 says why the score profile cannot
+    win there), so every setting must give the reference listing"""
+    q = os.path.join(GOLDEN, golden["query_fasta"])
+    for flags in (("-p", "S", "-u", "100"), ("-p", "Q"), ("-p", "A"), ("-p", "A", "-u", "0"), ("-u", "65535")):
+        p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-r", "40", *flags)
+        check_listing(p.stdout, golden, dbprefix, "blosum62_g10_e2", 40)
+        assert "Profile technique:\t\tQuery Profile in LDS" in p.stdout
+    assert run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-p", "X", check=False).returncode == 1
+    assert run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-u", "70000", check=False).returncode == 1
+
+
+@pytest.mark.gpu
+def test_search_mode2_auto_split(tmp_path):
+    """mode 2 without the test hook: the split comes from the measured host rate and a GPU probe (HETsearch.c:57,96-104
+    is the reference's dynamic counterpart).  The listing must equal mode 1's and the two legs must end within 2x of
+    each other."""
+    from swimm_amd import synth
+    qs = synth.make_queries(11, [375, 729, 1500])
+    lens = synth.lengths_lognormal(11, 400_000, 300.0, 0.55, 30, 4000)
+    db = synth.make_db(11, lens, planted=synth.planted_homologs(11, qs), with_titles=True)
+    fa, qfa, prefix = str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), str(tmp_path / "db")
+    synth.write_fasta(fa, synth.db_records(db))
+    synth.write_fasta(qfa, qs)
+    run("-S", "preprocess", "-i", fa, "-o", prefix)
+    threads = str(min(64, len(os.sched_getaffinity(0))))
+    auto = run("-S", "search", "-q", qfa, "-d", prefix, "-m", "2", "-c", threads, "-r", "25")
+    gpu = run("-S", "search", "-q", qfa, "-d", prefix, "-m", "1", "-r", "25")
+    assert [(t, L, hits) for t, L, hits in parse_report(auto.stdout)] == [(t, L, hits) for t, L, hits in parse_report(gpu.stdout)]
+    m = re.search(r"Host CPU share:\t\t\t(\d+) sequences \(([\d.]+) seconds\), MI355X (\d+) sequences \(([\d.]+) seconds\)", auto.stdout)
+    assert m, auto.stdout[-600:]
+    n_cpu, t_cpu, n_gpu, t_gpu = int(m.group(1)), float(m.group(2)), int(m.group(3)), float(m.group(4))
+    assert n_cpu >= 128 and n_cpu % 128 == 0 and n_cpu + n_gpu == db.n
+    assert 0.5 <= t_cpu / t_gpu <= 2.0, (n_cpu, t_cpu, t_gpu)

@@ -67,13 +67,18 @@ def test_c4_long_query_envnr_shape():
         _load(s, chunks.chunks)
         got, _ = s.search(chunks.vc * 128)
         plan = s.last_plan(0)
-        # the same recurrence cut differently: 4-wave workgroups (49+ passes), boundary buffer in 3+ runs
+        name = s.last_kernel_name(0)
+        # the same recurrence cut differently: 4-wave workgroups (39 group-resident passes); then one launch per pass with
+        # the boundary rows through HBM, the buffer in 3+ runs
         s.set_option("waves", 4)
-        s.set_option("bnd_mib", 300)
         other, _ = s.search(chunks.vc * 128)
+        s.set_option("resident", 0)
+        s.set_option("bnd_mib", 300)
+        third, _ = s.search(chunks.vc * 128)
+        assert s.last_stats()["launches"] >= 3 * s.last_plan(0)["passes"]
     chunks.close()
-    assert plan["passes"] >= 12
-    assert np.array_equal(got, other)
+    assert plan["passes"] >= 12 and name.endswith("true, true>(swimm::PipeParams)"), name     # group-resident passes are the default
+    assert np.array_equal(got, other) and np.array_equal(got, third)
     want, idx = oracle_matrix(w)
     _check_matrix(got[:, :w["n"]], want, idx, "c4")
 

@@ -92,7 +92,7 @@ size_t pipe_lds_bytes(int rows_per_wave, int waves);
 // which (tier, rows per wave, hand-over scheme) kernels exist
 bool pipe_has_variant(Mode mode, int rows_per_wave);
 // registers / occupancy of one instantiation (for the host-side launch plan)
-hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, int *num_regs);
+hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, bool resident, int *num_regs);
 // mangled symbol of the instantiation (nullptr when there is none)
 const char *pipe_kernel_symbol(Mode mode, int rows_per_wave, bool dynamic, bool resident);
 hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, int n_wg, const PipeParams &p, hipStream_t s);

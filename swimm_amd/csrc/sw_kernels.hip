@@ -614,16 +614,13 @@ static const void *kernel_ptr_t(Mode mode, int T)
     return nullptr;
 }
 
-hipError_t pipe_kernel_attributes(Mode mode, int T, int *num_regs)
+hipError_t pipe_kernel_attributes(Mode mode, int T, bool resident, int *num_regs)
 {
     hipFuncAttributes a;
-    const void *f = kernel_ptr_t<true, false>(mode, T);
+    const void *f = resident ? kernel_ptr_t<true, true>(mode, T) : kernel_ptr_t<true, false>(mode, T);
     if (!f) return hipErrorInvalidValue;
     hipError_t e = hipFuncGetAttributes(&a, f);
     if (e == hipSuccess) *num_regs = a.numRegs;
-    // the group-resident variant must fit the same occupancy: report the larger of the two
-    hipFuncAttributes b;
-    if (e == hipSuccess && hipFuncGetAttributes(&b, kernel_ptr_t<true, true>(mode, T)) == hipSuccess) *num_regs = a.numRegs > b.numRegs ? a.numRegs : b.numRegs;
     return e;
 }
 

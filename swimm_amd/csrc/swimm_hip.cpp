@@ -161,7 +161,7 @@ struct swimm_hip_ctx {
     int opt_wg_limit = 0;               // > 0: at most this many persistent workgroups per pipeline launch (tests: long per-workgroup item sequences on a small database)
     // caches that depend on the resident database / the code objects
     std::map<int, double> imbalance_cache;   // n_wg -> LPT makespan / mean load of the resident database (bulk groups)
-    int regs_cache[3][40] = {};         // VGPRs of sw_pipe_kernel<T, tier>, looked up once
+    int regs_cache[2][3][40] = {};      // VGPRs of sw_pipe_kernel<T, tier, dynamic, group-resident or not>, looked up once
     DevBuf<uint32_t> d_queue;           // one cursor per pipeline launch of a search
     uint32_t queue_next = 0;
     // queries (host copies; profiles are built per search because T/W may change)
@@ -217,10 +217,18 @@ int regs_to_waves_per_simd(int regs)
 
 // how many workgroups of W waves of the T-row kernel one CU holds (VGPRs: 8-register granule, 512 per SIMD
 // lane; LDS: 160 KiB)
-int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
+int kernel_regs(const swimm_hip_ctx *c, Mode mode, int T, bool resident, int *out)
 {
-    int &regs = const_cast<swimm_hip_ctx *>(c)->regs_cache[(int)mode][T];
-    if (regs == 0) HIP_TRY(pipe_kernel_attributes(mode, T, &regs));
+    int &regs = const_cast<swimm_hip_ctx *>(c)->regs_cache[resident ? 1 : 0][(int)mode][T];
+    if (regs == 0) HIP_TRY(pipe_kernel_attributes(mode, T, resident, &regs));
+    *out = regs;
+    return 0;
+}
+
+int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, bool resident, int *out)
+{
+    int regs = 0;
+    if (kernel_regs(c, mode, T, resident, &regs)) return 1;
     const int waves_cu = 4 * regs_to_waves_per_simd(regs);
     const size_t lds = pipe_lds_bytes(T, W);
     int n = std::min(waves_cu / W, (int)(163840 / lds));
@@ -228,6 +236,9 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, int *out)
     *out = std::max(1, n);
     return 0;
 }
+
+// a query of several passes runs the group-resident kernel (one launch) unless that is switched off
+bool resident_for(const swimm_hip_ctx *c, int passes) { return c->opt_dynamic && c->opt_resident && passes > 1; }
 
 // a run of consecutive device groups that is searched as one unit: the whole resident database (work lists cached),
 // or one chunk of a database that is still streaming in
@@ -310,9 +321,11 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
             const int passes = (strips + W - 1) / W;
             if (overlapped && passes != 1) continue;   // only one-pass queries take part in the rotation
             int per_cu = 1;
-            if (wgs_per_cu(c, mode, T, W, &per_cu)) return 1;
+            if (wgs_per_cu(c, mode, T, W, resident_for(c, passes), &per_cu)) return 1;
             if (room_for_lane_waves && !c->opt_T) {
-                const int alloc = (c->regs_cache[(int)mode][T] + 7) / 8 * 8;
+                int regs = 0;
+                if (kernel_regs(c, mode, T, resident_for(c, passes), &regs)) return 1;
+                const int alloc = (regs + 7) / 8 * 8;
                 if (alloc * ((per_cu * W + 3) / 4) > 512 - 80) continue;
             }
             // seconds: every pass aligns T x W rows against the whole resident database at the shape's rate, and costs
@@ -547,7 +560,7 @@ static bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &p
 
 // Group-resident passes (sw_pipe_kernel<.., RES = true>): one launch per multi-pass query, no launch boundary between passes
 // and no boundary rows shared between workgroups.
-static bool use_resident(const swimm_hip_ctx *c, const QueryPlan &qp) { return c->opt_dynamic && c->opt_resident && qp.passes > 1; }
+static bool use_resident(const swimm_hip_ctx *c, const QueryPlan &qp) { return resident_for(c, qp.passes); }
 // boundary scratch of that mode: per workgroup, the columns of the longest group of the list (64 lanes x 8 B each)
 static uint64_t resident_bnd_elems(const Plan &pl) { return pl.n_items ? (uint64_t)pl.n_wg * pl.queue_cols[0] * 64 : 0; }
 
@@ -854,13 +867,28 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     bool streaming = false;
     for (const ChunkRec &r : c->chunks) streaming = streaming || !r.uploaded;
     std::vector<Range> ranges;
+    std::vector<std::pair<size_t, size_t>> range_chunks;     // streaming: chunks [first, last) of every range
     if (streaming) {
         uint64_t mb = 16, mn = 1, mg = 1, mo = 1;
         for (const ChunkRec &r : c->chunks) {
-            Range rg; rg.g0 = r.group0; rg.g1 = r.group0 + r.n_groups; rg.cols = r.cols; ranges.push_back(rg);
             if (r.uploaded) continue;
             mb = std::max<uint64_t>(mb, r.kind == 0 ? r.vD : r.code_bytes); mn = std::max<uint64_t>(mn, r.group_count);
             mg = std::max<uint64_t>(mg, r.n_groups); mo = std::max<uint64_t>(mo, r.off.size());
+        }
+        // Consecutive chunks form a range; every range is about twice the one before it (the first is one chunk): the
+        // link copies faster than the kernels consume, so while range k is aligned range k+1 arrives in full, the first
+        // kernel starts after one chunk's copy, and most of the database is still aligned by a few large launches.
+        uint64_t prev = 0;
+        for (size_t i = 0; i < c->chunks.size();) {
+            Range rg; rg.g0 = c->chunks[i].group0; rg.g1 = rg.g0; rg.cols = 0;
+            const size_t first = i;
+            do {
+                rg.g1 += c->chunks[i].n_groups; rg.cols += c->chunks[i].cols;
+                ++i;
+            } while (i < c->chunks.size() && rg.cols < 2 * prev);
+            prev = rg.cols;
+            ranges.push_back(rg);
+            range_chunks.push_back({first, i});
         }
         // the upload scratch grows now, not between two chunks (growing frees the old buffer)
         HIP_TRY(c->up_b.reserve(mb)); HIP_TRY(c->up_n.reserve(mn)); HIP_TRY(c->up_disp.reserve(mn));
@@ -930,13 +958,15 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     // the work lists of a (range, launch shape): cached for the resident database, temporary for a streaming chunk
     auto plan_of = [&](size_t ri, uint32_t q, DbPlan **out) -> int {
         int per_cu = 1;
-        if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, &per_cu)) return 1;
+        if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, resident_for(c, qps[q].passes), &per_cu)) return 1;
         const int n_wg = n_workgroups(c, per_cu);
         if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0, out);
         auto it = stream_plans[ri].find(n_wg);
         if (it == stream_plans[ri].end()) {
             DbPlan &dp = stream_plans[ri][n_wg];
-            if (make_db_plan(c, main_mode, n_wg, false, ranges[ri], c->chunks[ri].lens_known, dp)) return 1;
+            bool exact = true;
+            for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[ci].lens_known;
+            if (make_db_plan(c, main_mode, n_wg, false, ranges[ri], exact, dp)) return 1;
             *out = &dp;
         } else {
             *out = &it->second;
@@ -950,6 +980,32 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         uint64_t need_bnd = 0;
         size_t tail_cols = 0, tail_items = 0, launch_total = 16;
         int max_passes = 1;
+        for (uint32_t q = 0; q < qn; ++q) max_passes = std::max(max_passes, (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
+        if (streaming) {
+            // a range's work lists are built when its turn comes (the GPU is busy with the range before it by then):
+            // size the shared buffers from the geometry alone
+            const uint64_t budget = bnd_budget_cols(c);
+            for (size_t ri = 0; ri < ranges.size(); ++ri) {
+                const std::vector<uint8_t> is_tail = main_mode != Mode::I32 ? pick_tail(c, ranges[ri]) : std::vector<uint8_t>(ranges[ri].g1 - ranges[ri].g0, 0);
+                size_t t_items = 0, t_cols = 0;
+                uint32_t longest_main = 0;
+                for (uint32_t g = ranges[ri].g0; g < ranges[ri].g1; ++g) {
+                    if (is_tail[g - ranges[ri].g0]) { t_items += 64; t_cols += (size_t)64 * c->groups[g].ncols; }
+                    else longest_main = std::max(longest_main, c->groups[g].ncols);
+                }
+                tail_items = std::max(tail_items, t_items);
+                tail_cols = std::max(tail_cols, t_cols);
+                for (uint32_t q = 0; q < qn; ++q) {
+                    if (qps[q].passes <= 1) { launch_total += 2; continue; }
+                    int per_cu = 1;
+                    if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, resident_for(c, qps[q].passes), &per_cu)) return 1;
+                    const uint64_t cols = ranges[ri].cols * (main_mode == Mode::I32 ? 2 : 1);
+                    if (use_resident(c, qps[q])) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_main * 64);
+                    else need_bnd = std::max<uint64_t>(need_bnd, std::min<uint64_t>(cols, std::max<uint64_t>(budget, longest_main)) * 64);
+                    launch_total += (size_t)qps[q].passes * (size_t)(cols / std::max<uint64_t>(budget, 1) + 2);
+                }
+            }
+        } else
         for (size_t ri = 0; ri < ranges.size(); ++ri)
             for (uint32_t q = 0; q < qn; ++q) {
                 DbPlan *dp = nullptr;
@@ -969,7 +1025,6 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 launch_total += (size_t)qps[q].passes * std::max<size_t>(nsegs, 2);   // two kernels per pass when the list is split over two streams
                 tail_cols = std::max<size_t>(tail_cols, dp->tail.cols);
                 tail_items = std::max<size_t>(tail_items, dp->tail.n);
-                max_passes = std::max(max_passes, (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
             }
         HIP_TRY(c->d_bnd.reserve(need_bnd));
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
@@ -997,10 +1052,11 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     }
     for (size_t ri = 0; ri < ranges.size(); ++ri) {
         if (streaming) {
-            ChunkRec &ch = c->chunks[ri];
-            if (upload_chunk(c, ch)) return 1;               // returns when the host bytes are consumed; the tile kernel is still running
-            HIP_TRY(hipStreamWaitEvent(c->stream, ch.ready, 0));
-            HIP_TRY(hipStreamWaitEvent(c->stream2, ch.ready, 0));
+            for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci)
+                if (upload_chunk(c, c->chunks[ci])) return 1;   // returns when the host bytes are consumed; the tile kernel is still running
+            ChunkRec &last = c->chunks[range_chunks[ri].second - 1];   // the upload stream is in order: its last chunk's event covers the range
+            HIP_TRY(hipStreamWaitEvent(c->stream, last.ready, 0));
+            HIP_TRY(hipStreamWaitEvent(c->stream2, last.ready, 0));
         }
         // Longest query first: its promotion re-runs (a handful of long serial chains on stream 3) then overlap
         // the bulk kernels of the shorter queries instead of running alone at the end.

@@ -340,6 +340,8 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
             }
         }
     }
+    // (no admissible shape leaves a lane-systolic wave its registers, e.g. under a max_waves cap: the tail then shares)
+    if (best_cost < 0 && room_for_lane_waves) return choose_plan(c, mode, m, false, overlapped, out);
     if (best_cost < 0) { fail("no kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W); return 1; }
     return 0;
 }

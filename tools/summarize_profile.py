@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Condenses gpurun_out/prof_<tag>/ (written by tools/profile_bench.sh) into the files under profiles/.
 
-usage: python tools/summarize_profile.py <tag> [round-prefix, default r02]
-  profiles/<rnd>_c2_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied)
-  profiles/<rnd>_c2_pmc_summary.csv    per-counter mean per launch of the dominant kernel
-  profiles/<rnd>_pmc_traffic.json      HBM bytes per launch with the gfx950 corrections
-                                       (MI355X_MICROARCH.md: FETCH_SIZE x2 on streaming reads, KB units)
+usage: python tools/summarize_profile.py <tag> [round-prefix, default r02] [label, default c2]
+  profiles/<rnd>_<label>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied)
+  profiles/<rnd>_<label>_pmc_summary.csv    per-counter mean per launch of the dominant kernel
+  profiles/<rnd>_pmc_traffic_<label>.json   HBM bytes per launch with the gfx950 corrections
+                                            (MI355X_MICROARCH.md: FETCH_SIZE x2 on streaming reads, KB units)
 """
 import csv
 import glob
@@ -25,6 +25,7 @@ def find(base, pat):
 def main():
     tag = sys.argv[1]
     rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+    label = sys.argv[3] if len(sys.argv) > 3 else "c2"
     base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = os.path.join(ROOT, "profiles")
 
@@ -34,7 +35,7 @@ def main():
     rows = list(csv.DictReader(open(stats[0])))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     dominant = rows[0]["Name"]
-    with open(os.path.join(out, f"{rnd}_c2_kernel_stats.csv"), "w") as f:
+    with open(os.path.join(out, f"{rnd}_{label}_kernel_stats.csv"), "w") as f:
         f.write(open(stats[0]).read())
 
     per = defaultdict(lambda: defaultdict(float))   # counter -> dispatch id -> value (summed over XCD rows)
@@ -48,8 +49,8 @@ def main():
                 if dispatch is None:
                     dispatch = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
                                                   "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Kernel_Name") if k in r}
-    with open(os.path.join(out, f"{rnd}_c2_pmc_summary.csv"), "w") as f:
-        f.write(f"# rocprofv3 --pmc passes (tools/profile_bench.sh {tag}), bench.py c2 full scale, default path\n")
+    with open(os.path.join(out, f"{rnd}_{label}_pmc_summary.csv"), "w") as f:
+        f.write(f"# rocprofv3 --pmc passes (tools/profile_bench.sh / profile_cmd.sh {tag}), workload {label}, default path\n")
         f.write(f"# dispatch: {json.dumps(dispatch)}\n")
         f.write("counter,launches,mean_per_launch\n")
         for c in sorted(per):
@@ -75,7 +76,7 @@ def main():
             "workload_key": (cfg.get("workload", "c2").split(":")[0]), "scale": cfg.get("scale", 1.0), "plan": cfg.get("plan"),
             "sq_insts_valu_per_launch": mean("SQ_INSTS_VALU"),
             "kernel_avg_ns": float(rows[0]["AverageNs"]), "kernel_calls": int(rows[0]["Calls"]),
-            "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE, separate passes (profiles/{rnd}_c2_pmc_summary.csv)",
+            "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE, separate passes (profiles/{rnd}_{label}_pmc_summary.csv)",
             "kernel": dominant,
             "workload": cfg.get("workload", "bench.py c2, 1M sequences, 375-aa query"),
             "FETCH_SIZE_KB": fetch,
@@ -84,7 +85,7 @@ def main():
             "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
             "grbm_gui_active_sum_over_8_xcd": mean("GRBM_GUI_ACTIVE"),
         }
-        json.dump(traffic, open(os.path.join(out, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
+        json.dump(traffic, open(os.path.join(out, f"{rnd}_pmc_traffic_{label}.json"), "w"), indent=1)
     print("dominant kernel:", dominant)
     print("avg ns:", rows[0]["AverageNs"], "calls:", rows[0]["Calls"])
     for c in sorted(per):

@@ -181,14 +181,13 @@ static uint64_t hybrid_split(const swimm_hip_api *api, const swimm_options *o, c
         return n < db->count ? n : 0;
     }
     uint64_t sample = 0, sample_res = 0;
-    while (sample < db->count && sample_res * q->m[0] < 100000000ull) sample_res += db->lengths[sample++];
-    sample = sample / vl * vl;
-    if (sample == 0 || sample == db->count) return 0;
-    swimm_queries q0 = *q;
-    q0.count = 1;                                   /* first (shortest) query only */
+    while (sample < db->count && sample_res * q->Q < 400000000ull) sample_res += db->lengths[sample++];
+    sample = (sample + vl - 1) / vl * vl;
+    if (sample == 0 || sample >= db->count) return 0;
+    swimm_queries q0 = *q;                          /* the whole batch: the host's rate depends on the query length */
     leg_stats st = {0, 0, 0, 0};
-    int32_t s1[1];
-    int64_t i1[1];
+    int32_t *s1 = (int32_t *)malloc(q->count * sizeof(int32_t));
+    int64_t *i1 = (int64_t *)malloc(q->count * sizeof(int64_t));
     swimm_single_chunk sc;
     int rc = swimm_assemble_single_chunk(db->lengths, db->codes, sample, o->vector_length, o->cpu_block_size, &sc);
     if (rc) die_host(rc);
@@ -198,7 +197,8 @@ static uint64_t hybrid_split(const swimm_hip_api *api, const swimm_options *o, c
     swimm_single_chunk_free(&sc);
     sample_res = 0;
     for (uint64_t i = 0; i < sample; ++i) sample_res += db->lengths[i];
-    const double host_rate = (double)sample_res * q->m[0] / (st.seconds > 1e-6 ? st.seconds : 1e-6);   /* cells per second */
+    free(s1); free(i1);
+    const double host_rate = (double)sample_res * (double)q->Q / (st.seconds > 1e-6 ? st.seconds : 1e-6);   /* cells per second */
 
     /* GPU probe: the last sequences of the sorted database (the GPUs' end), at most 64 MB of residues */
     uint64_t pn = 0, pres = 0;

@@ -5,8 +5,9 @@
       passes + the binary16 -> int16 -> int32 promotion ladder of 20 queries in flight on three streams.
   c4  the 5478-aa query x 1 000 000 Env-NR-shaped sequences, BLOSUM62: 25 passes through HBM boundary rows.
   c5  20 queries x an Env-NR-shaped database, PAM250, statically sharded over 8 (virtual) GPUs: every workgroup
-      aligns more than 32 groups back to back (the 32-entry ring of item ids in LDS wraps), the pass-boundary buffer
-      is cut into >= 2 runs, and the per-device top-20 lists are merged on the host.
+      aligns more than 32 groups back to back (the 32-entry ring of item ids in LDS wraps), through group-resident passes
+      on the even devices and through one launch per pass with the boundary buffer cut into >= 2 runs on the odd ones,
+      and the per-device top-20 lists are merged on the host.
 
 The checker is the reference's own AVX2 path (oracle/_ref/libswimm_ref.so = cpu_search_avx2_sp, CPUsearch.c:482-967,
 compiled by oracle/Makefile) when it is present, else the C restatement oracle/sw_oracle.c; the WHOLE score matrix is
@@ -104,7 +105,9 @@ def test_c5_envnr_pam250_eight_way_shard(monkeypatch):
             # full size, where no Env-NR group is long beside a CU's load); boundary buffer: two runs
             s.set_option("wg_limit", 4)
             s.set_option("tail_mode", 2)
-            s.set_option("bnd_mib", max(1, int(cols * 512 * 0.55) >> 20))
+            if d % 2:    # odd devices: one launch per pass, the boundary rows through HBM in two runs; even: group-resident passes
+                s.set_option("resident", 0)
+                s.set_option("bnd_mib", max(1, int(cols * 512 * 0.55) >> 20))
             s.set_queries(q["a"], q["m"], q["disp"], sm, 10, 2)
             _load(s, mine)
             assert groups >= 4 * 40, groups
@@ -112,7 +115,10 @@ def test_c5_envnr_pam250_eight_way_shard(monkeypatch):
             st = s.last_stats()
             plans = [s.last_plan(k) for k in range(len(w["m"]))]
             multi = [p["passes"] for p in plans if p["passes"] > 1]
-            assert multi and st["launches"] >= sum(p["passes"] for p in plans) + sum(multi), (st, plans)   # >= 2 boundary runs per multi-pass query
+            if d % 2:
+                assert multi and st["launches"] >= sum(p["passes"] for p in plans) + sum(multi), (st, plans)   # >= 2 boundary runs per multi-pass query
+            else:
+                assert multi and len(plans) <= st["launches"] < len(plans) + 20, (st, plans)                   # one launch per query + promotion re-runs
             s.set_option("wg_limit", 64)                       # (the listing itself does not need the slow four-workgroup shape again)
             ts, ti, _ = s.search_topr(20, w["n"])
         lists_s.append(ts)

@@ -88,7 +88,7 @@ size_t lane_lds_bytes(int rows_per_lane);
 // rows_per_lane: kLaneRows (any query), or 4 / 2 for a one-pass launch of a query of <= 256 / <= 128 rows
 hipError_t launch_lane(Mode mode, int rows_per_lane, int n_wg, const LaneParams &p, hipStream_t s);
 
-size_t pipe_lds_bytes(int rows_per_wave, int waves);
+size_t pipe_lds_bytes(int rows_per_wave, int waves, bool resident);
 // which (tier, rows per wave, hand-over scheme) kernels exist
 bool pipe_has_variant(Mode mode, int rows_per_wave);
 // registers / occupancy of one instantiation (for the host-side launch plan)

@@ -156,9 +156,13 @@ __host__ __device__ constexpr int prof_row_bytes(int rows) { return rows * 2 + 1
 __host__ __device__ constexpr int strip_lds_rows(int T) { return (T + 7) & ~7; }
 // LDS of one workgroup: query profile | hand-over ring (2 chunk slots per wave) | control words
 constexpr int kSeqRing = 32;      // item ids of the workgroup's sequence, published by wave 0 (dynamic mode)
-size_t pipe_lds_bytes(int T, int W)
+// group-resident passes: per wave, a lane-linear landing area for the next pass's strip of the profile (filled by
+// global_load_lds, i.e. without registers)
+__host__ __device__ constexpr int strip_stage_dwords(int T) { return (kCodes * (T / 2) + 63) / 64 * 64; }
+size_t pipe_lds_bytes(int T, int W, bool resident)
 {
-    return round16((size_t)kCodes * prof_row_bytes(strip_lds_rows(T) * W)) + (size_t)W * 2 * kChunkCols * 64 * sizeof(uint2) + (kSeqRing + 4) * 4;
+    return round16((size_t)kCodes * prof_row_bytes(strip_lds_rows(T) * W)) + (size_t)W * 2 * kChunkCols * 64 * sizeof(uint2) + (kSeqRing + 4) * 4 +
+           (resident ? (size_t)W * strip_stage_dwords(T) * 4 : 0);
 }
 
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
@@ -284,7 +288,28 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, out_slot = 0, n = 0, next_it = kNoItem;
     uint32_t pass = 0, len = 0;            // RES: pass of the current item; steps the item-pass occupies (>= nch)
     int staged_pass = -1;                  // RES: which pass's rows this wave's strip of the LDS profile holds
+    // RES: the strip's profile rows of the NEXT pass are requested during the last chunk of the current item-pass, straight
+    // into a per-wave landing area in LDS (global_load_lds: no registers), so that the switch itself is a handful of LDS
+    // reads and writes.  (Fetching them at the switch stalled the wave for an L2 round trip and, through the step barrier,
+    // the whole workgroup: W stalls per item-pass, -3 % on c2, -10 % with 16 waves.)
+    constexpr int NPF = strip_stage_dwords(T) / 64;
+    uint32_t *const stage = (uint32_t *)(total_lds + 4) + (size_t)k * strip_stage_dwords(T);
+    int pf_pass = -1;
     const uint32_t passes = RES ? p.passes : 1u;
+    auto fetch_strip = [&](uint32_t ps) {
+        const uint32_t row0 = ps * (uint32_t)(W * T) + (uint32_t)(k * T);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));     // opaque: otherwise the per-lane addresses are hoisted out of the main loop and held in 2 x NPF registers
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            int idx = ln + 64 * i;
+            if (idx >= kCodes * (T / 2)) idx = 0;        // (landing slots past the strip's last dword are never read)
+            const int d = idx / (T / 2), x = idx - d * (T / 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(p.prof + (size_t)d * p.prof_stride + row0 + 2 * x),
+                                             (__attribute__((address_space(3))) void *)(stage + 64 * i), 4, 0, 0);
+        }
+        pf_pass = (int)ps;
+    };
     uint64_t bnd_off = 0;
     const uint8_t *dbp = nullptr;
     uint32_t nwa = 0, nwb = 0;     // residues of the wave's next chunk, loaded one step ahead
@@ -324,20 +349,31 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 if (RES && staged_pass != (int)pass) {
                     // this wave's strip of the profile for this pass: rows pass*W*T + k*T .. + T of all 25 codes.  Only
                     // this wave reads that part of the LDS profile, so nobody has to be waited for.
-                    const uint32_t row0 = pass * (uint32_t)(W * T) + (uint32_t)(k * T);
-                    for (int idx = lane; idx < kCodes * (T / 2); idx += 64) {
+                    if (pf_pass != (int)pass) fetch_strip(pass);       // (first item of the workgroup: nothing was requested ahead)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows have landed (an LDS-DMA counts as a vector-memory operation)
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) {
+                        const int idx = ln + 64 * i;
                         const int d = idx / (T / 2), x = idx - d * (T / 2);
-                        uint32_t v = *(const uint32_t *)(p.prof + (size_t)d * p.prof_stride + row0 + 2 * x);
+                        uint32_t v = *(volatile uint32_t *)(stage + idx);
                         if (M == 2) {
                             const v2s sv = as_v2s(v);
                             v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)sv.x, (_Float16)(float)sv.y});
                         }
-                        *(uint32_t *)(prof_lds + d * PS + (k * TP + 2 * x) * 2) = v;
+                        if (idx < kCodes * (T / 2)) *(uint32_t *)(prof_lds + d * PS + (k * TP + 2 * x) * 2) = v;
                     }
                     staged_pass = (int)pass;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
+            }
+            if (RES && cc + 1 == nch && passes > 1) {
+                // last chunk of this item-pass: request the rows of the pass that follows (the next pass of this group, or
+                // pass 0 of the next one); they arrive while this chunk is computed
+                const uint32_t np = pass + 1 < passes ? pass + 1 : 0u;
+                if ((int)np != staged_pass) fetch_strip(np);
             }
             if (!RES || cc < nch) {               // (RES: a short group idles here to the pipeline's depth between two passes)
             // database residues of this chunk: 4 columns of the lane's sequence(s).  They were requested one
@@ -543,7 +579,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 template <int T, int M, bool DYN, bool RES>
 static hipError_t launch_one(int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
-    const size_t lds = pipe_lds_bytes(T, W);
+    const size_t lds = pipe_lds_bytes(T, W, RES);
     hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, M, DYN, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((sw_pipe_kernel<T, M, DYN, RES>), dim3(n_wg), dim3(W * 64), lds, s, p);

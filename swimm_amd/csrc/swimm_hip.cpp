@@ -230,7 +230,7 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, bool resident, i
     int regs = 0;
     if (kernel_regs(c, mode, T, resident, &regs)) return 1;
     const int waves_cu = 4 * regs_to_waves_per_simd(regs);
-    const size_t lds = pipe_lds_bytes(T, W);
+    const size_t lds = pipe_lds_bytes(T, W, resident);
     int n = std::min(waves_cu / W, (int)(163840 / lds));
     if (c->opt_wgs_per_cu > 0) n = c->opt_wgs_per_cu;
     *out = std::max(1, n);

@@ -153,13 +153,16 @@ struct swimm_hip_ctx {
     int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
     int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
     int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
-    int opt_resident = 1;               // 1: a multi-pass query runs as ONE launch whose workgroups take every group through all its passes back to back
+    int opt_resident = 0;               // 1: a multi-pass query runs as ONE launch whose workgroups take every group through all its passes back to back
+    int opt_lane_room = -1;             // launch shapes must leave a lane-systolic wave its registers: -1 = when the database has a long-sequence tail, 0 never, 1 always
     int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
     int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
     int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
     int opt_lane_acquire = 0;           // 1: chained lane passes take an agent-scope acquire after every progress poll (default: sc1 loads only)
     int opt_wg_limit = 0;               // > 0: at most this many persistent workgroups per pipeline launch (tests: long per-workgroup item sequences on a small database)
     // caches that depend on the resident database / the code objects
+    std::vector<uint32_t> bulk_cols_sorted;  // lengths of the groups the pipeline kernel aligns, longest first (built on demand)
+    uint64_t bulk_cols_total = 0;
     std::map<int, double> imbalance_cache;   // n_wg -> LPT makespan / mean load of the resident database (bulk groups)
     int regs_cache[2][3][40] = {};      // VGPRs of sw_pipe_kernel<T, tier, dynamic, group-resident or not>, looked up once
     DevBuf<uint32_t> d_queue;           // one cursor per pipeline launch of a search
@@ -207,6 +210,7 @@ void release_plans(swimm_hip_ctx *c)
     for (auto &kv : c->plans) { kv.second.main.release(); kv.second.tail.release(); }
     c->plans.clear();
     c->imbalance_cache.clear();
+    c->bulk_cols_sorted.clear();
 }
 
 int regs_to_waves_per_simd(int regs)
@@ -262,20 +266,30 @@ double plan_imbalance(swimm_hip_ctx *c, int n_wg)
 {
     auto it = c->imbalance_cache.find(n_wg);
     if (it != c->imbalance_cache.end()) return it->second;
-    const std::vector<uint8_t> is_tail = pick_tail(c, whole_range(c));
-    std::vector<uint32_t> cols;
-    uint64_t total = 0;
-    for (uint32_t g = 0; g < c->groups.size(); ++g)
-        if (!is_tail[g]) { cols.push_back(c->groups[g].ncols); total += c->groups[g].ncols; }
+    if (c->bulk_cols_sorted.empty() && !c->groups.empty()) {     // once per database: the bulk groups' lengths, longest first
+        const std::vector<uint8_t> is_tail = pick_tail(c, whole_range(c));
+        c->bulk_cols_total = 0;
+        for (uint32_t g = 0; g < c->groups.size(); ++g)
+            if (!is_tail[g]) { c->bulk_cols_sorted.push_back(c->groups[g].ncols); c->bulk_cols_total += c->groups[g].ncols; }
+        std::sort(c->bulk_cols_sorted.begin(), c->bulk_cols_sorted.end(), std::greater<uint32_t>());
+    }
+    const std::vector<uint32_t> &cols = c->bulk_cols_sorted;
+    const uint64_t total = c->bulk_cols_total;
     double r = 1.0;
     if (!cols.empty() && total > 0) {
-        std::sort(cols.begin(), cols.end(), std::greater<uint32_t>());
         const int n = std::max(1, std::min<int>(n_wg, (int)cols.size()));
-        std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> heap;
-        for (int w = 0; w < n; ++w) heap.push(0);
-        uint64_t mx = 0;
-        for (uint32_t x : cols) { uint64_t l = heap.top() + x; heap.pop(); heap.push(l); mx = std::max(mx, l); }
-        r = (double)mx / ((double)total / n_wg);   // fewer groups than workgroups: the idle ones count
+        // Longest-first greedy.  With many groups per workgroup the schedule ends within one short group of the mean
+        // load; the exact simulation only matters (and is only run) while a workgroup gets fewer than 64 groups.
+        if (cols.size() >= (size_t)64 * n) {
+            const double mean = (double)total / n_wg;
+            r = std::max((double)cols[0], mean + 0.5 * cols[cols.size() - cols.size() / 8 - 1]) / mean;
+        } else {
+            std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> heap;
+            for (int w = 0; w < n; ++w) heap.push(0);
+            uint64_t mx = 0;
+            for (uint32_t x : cols) { uint64_t l = heap.top() + x; heap.pop(); heap.push(l); mx = std::max(mx, l); }
+            r = (double)mx / ((double)total / n_wg);   // fewer groups than workgroups: the idle ones count
+        }
     }
     c->imbalance_cache[n_wg] = r;
     return r;
@@ -332,7 +346,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
             // a launch (pipeline fill and drain, staging, the last workgroups running alone: ~0.15 ms, which is what
             // makes fewer, taller passes the better plan on a database of 1e8 residues)
             const double pass_s = (double)c->total_cols * kGroupSeqs * T * W / ((double)kShapeGcups[ti][W - 1] * 1e9)
-                                  * (passes > 1 && W < 8 ? 1.17 : 1.0) * (overlapped ? 1.0 : plan_imbalance(c, n_workgroups(c, per_cu)));
+                                  * (overlapped ? 1.0 : plan_imbalance(c, n_workgroups(c, per_cu)));
             const double cost = passes * (pass_s + 150e-6);
             if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
                 best_cost = cost;
@@ -916,6 +930,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     for (const GroupDesc &g : c->groups) longest_cols = std::max(longest_cols, g.ncols);
     if (c->opt_tail_mode != 2 && main_mode != Mode::I32)
         lane_room = c->opt_tail_mode == 1 || (double)longest_cols > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
+    if (c->opt_lane_room >= 0) lane_room = c->opt_lane_room != 0 && main_mode != Mode::I32;
     std::vector<QueryPlan> qps(qn);
     std::vector<uint8_t> rotated(qn, 0);
     uint32_t n_short = 0;
@@ -1590,6 +1605,9 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "lane_rows")) {
         c->opt_lane_rows = value != 0;
+    } else if (!strcmp(key, "lane_room")) {
+        if (value < -1 || value > 1) return fail("lane_room must be -1 (auto), 0 or 1");
+        c->opt_lane_room = value;
     } else if (!strcmp(key, "resident")) {
         c->opt_resident = value != 0;
     } else if (!strcmp(key, "split")) {

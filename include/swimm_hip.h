@@ -123,10 +123,14 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *   "tail_frac"      a group is "unusually long" above this percentage of a CU's mean load (default 50)
  *   "dynamic"        1 = default: workgroups pull groups from a global queue; 0 = static longest-first partition
  *   "lane_rows"      1 = default: one-pass lane-systolic launches of short queries use 2 / 4 query rows per lane; 0 = always 8
- *   "resident"       1 = default: a query of two or more passes is ONE launch; each workgroup takes a group through all its
- *                    passes back to back, the strip boundary in scratch only it touches (no launch boundary, no boundary
- *                    rows through HBM between workgroups); 0 = one launch per pass ("split", "bnd_mib" then apply)
- *   "split"          (resident = 0) 1 = default: a query of three or more passes runs the even- and odd-ranked groups as two kernels on two streams,
+ *   "resident"       0 = default: one launch per pass of a multi-pass query ("split", "bnd_mib" apply); 1 = ONE launch, each
+ *                    workgroup takes a group through all its passes back to back, the strip boundary in scratch only it
+ *                    touches (no launch boundary; measured equal to the default within 1 %)
+ *   "lane_room"      -1 = default: launch shapes leave a lane-systolic wave its registers when the database has a long-sequence
+ *                    tail; 0 = never; 1 = always
+ *   "alternate"      1 = default: in a batch with two or more multi-pass queries, consecutive queries run their passes on two
+ *                    streams, so that the end of every launch is covered by a kernel of the other query; 0 = one stream
+ *   "split"          1 = default: a query of three or more passes runs the even- and odd-ranked groups as two kernels on two streams,
  *                    so that the end of one launch is covered by the other; 0 = one kernel per pass
  *   "lazy_upload"    0 = default: add_chunk / add_sequences copy the caller's buffers before they return; 1 = they only
  *                    record them and the next search streams the chunks in, copying and tiling chunk k+1 while chunk k

@@ -155,6 +155,7 @@ struct swimm_hip_ctx {
     int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
     int opt_resident = 0;               // 1: a multi-pass query runs as ONE launch whose workgroups take every group through all its passes back to back
     int opt_lane_room = -1;             // launch shapes must leave a lane-systolic wave its registers: -1 = when the database has a long-sequence tail, 0 never, 1 always
+    int opt_alternate = 1;              // 1: the passes of consecutive multi-pass queries alternate between two streams
     int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
     int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
     int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
@@ -185,7 +186,7 @@ struct swimm_hip_ctx {
     // scratch
     DevBuf<int32_t> d_scores;
     DevBuf<int16_t> d_prof;
-    DevBuf<uint2> d_bnd;
+    DevBuf<uint2> d_bnd, d_bnd_b;       // pass-boundary rows; the second one for the queries whose passes run on stream_b
     DevBuf<int64_t> d_gbase;
     DevBuf<uint32_t> d_gvalid;
     DevBuf<unsigned long long> d_keys;
@@ -535,11 +536,11 @@ int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool whole_db, DbPlan **o
     return 0;
 }
 
-void fill_common(const swimm_hip_ctx *c, const QueryPlan &qp, PipeParams &p)
+void fill_common(const swimm_hip_ctx *c, const QueryPlan &qp, PipeParams &p, uint2 *bnd)
 {
     p.prof = c->d_prof.p + qp.prof_off;
     p.prof_stride = qp.mpad;
-    p.bnd = c->d_bnd.p;
+    p.bnd = bnd;
     p.goe = c->open_gap + c->extend_gap;
     p.ge = c->extend_gap;
 }
@@ -581,13 +582,13 @@ static bool use_resident(const swimm_hip_ctx *c, const QueryPlan &qp) { return r
 static uint64_t resident_bnd_elems(const Plan &pl) { return pl.n_items ? (uint64_t)pl.n_wg * pl.queue_cols[0] * 64 : 0; }
 
 // `st`: stream of the one-kernel-per-pass path (one-pass queries rotate over three streams)
-int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st, bool allow_split)
+int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st, bool allow_split, DevBuf<uint2> &bnd)
 {
     if (use_resident(c, qp)) {
         PipeParams p{};
-        fill_common(c, qp, p);
+        fill_common(c, qp, p, bnd.p);
         if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
-        if (c->d_bnd.cap < resident_bnd_elems(pl)) return fail("internal: boundary scratch too small");
+        if (bnd.cap < resident_bnd_elems(pl)) return fail("internal: boundary scratch too small");
         p.items = pl.queue_items.p;
         p.n_items = pl.n_items;
         const int n_wg = (int)std::min<uint32_t>((uint32_t)pl.n_wg, pl.n_items);
@@ -609,7 +610,7 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
     uint64_t seg_cols = pl.bnd_cols;
     if (c->opt_dynamic && qp.passes > 1) boundary_segments(c, pl, segs, &seg_cols);
     else segs.push_back({0u, pl.n_items});
-    if (qp.passes > 1) HIP_TRY(c->d_bnd.reserve(seg_cols * 64));
+    if (qp.passes > 1 && bnd.cap < seg_cols * 64) return fail("internal: boundary buffer too small");
     if (allow_split && use_split(c, qp, pl, segs.size())) {
         HIP_TRY(hipEventRecord(c->ev_a, c->stream));               // stream B joins after everything queued so far
         HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_a, 0));
@@ -619,7 +620,7 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
         for (int pass = 0; pass < qp.passes; ++pass)
             for (int h = 0; h < 2; ++h) {
                 PipeParams p{};
-                fill_common(c, qp, p);
+                fill_common(c, qp, p, bnd.p);
                 if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
                 p.items = pl.split_items.p + (h ? pl.split_n[0] : 0);
                 p.n_items = pl.split_n[h];
@@ -648,7 +649,7 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
         const int n_wg = c->opt_dynamic ? (int)std::min<uint32_t>((uint32_t)pl.n_wg, sg.second - sg.first) : pl.n_wg;
         for (int pass = 0; pass < qp.passes; ++pass) {
             PipeParams p{};
-            fill_common(c, qp, p);
+            fill_common(c, qp, p, bnd.p);
             p.items = pl.items.p;
             p.wg_first = pl.wg_first.p;
             p.wg_chunks = pl.wg_chunks.p;
@@ -658,7 +659,7 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
                 p.n_items = sg.second - sg.first;
                 p.max_steps = (uint32_t)std::min<uint64_t>(seg_chunks + kMaxWaves + 1, 0x3ffffff0u);
                 p.queue = c->d_queue.p + c->queue_next++;
-                p.bnd = c->d_bnd.p - col0 * 64;      // the items' offsets count columns from the start of the whole list
+                p.bnd = bnd.p - col0 * 64;      // the items' offsets count columns from the start of the whole list
             }
             p.r0 = (uint32_t)(pass * qp.W * qp.T);
             p.first_pass = pass == 0;
@@ -957,6 +958,12 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         qps[q].prof_off = prof_elems;
         prof_elems += (size_t)kCodes * qps[q].mpad;
     }
+    // Two or more multi-pass queries: their passes alternate between the two bulk streams (each with a boundary buffer
+    // of its own), so that the end of every launch -- the last workgroups finishing alone -- is covered by a kernel of
+    // the other query.  (Within ONE such query the even/odd split of run_passes does the same.)
+    uint32_t n_multi = 0;
+    for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && qps[q].passes > 1;
+    const bool alternate = n_multi >= 2 && c->opt_alternate && !streaming;
     std::vector<int16_t> prof(prof_elems, 0);
     for (uint32_t q = 0; q < qn; ++q) {
         const int8_t *qa = c->qcodes.data() + qdisp[q];
@@ -1044,6 +1051,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 tail_items = std::max<size_t>(tail_items, dp->tail.n);
             }
         HIP_TRY(c->d_bnd.reserve(need_bnd));
+        if (alternate) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
@@ -1060,7 +1068,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
     HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_ready, 0));
-    uint32_t one_pass_seen = 0;
+    uint32_t one_pass_seen = 0, multi_seen = 0;
     HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
     while (c->ev_query.size() < 2 * (size_t)qn) {
         hipEvent_t e;
@@ -1106,8 +1114,10 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 default: tail_stream = bulk_stream = c->stream2; break;
                 }
             }
+            DevBuf<uint2> *bnd = &c->d_bnd;
+            if (alternate && qps[q].passes > 1 && !rotated[q] && (multi_seen++ & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
             if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
-            if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row, bulk_stream, !streaming)) return 1;
+            if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row, bulk_stream, !streaming && !alternate, *bnd)) return 1;
             if (ri + 1 == ranges.size()) {
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
@@ -1304,7 +1314,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
-    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release();
+    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release();
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_a.release(); c->tail_scratch_b.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1610,6 +1620,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         c->opt_lane_room = value;
     } else if (!strcmp(key, "resident")) {
         c->opt_resident = value != 0;
+    } else if (!strcmp(key, "alternate")) {
+        c->opt_alternate = value != 0;
     } else if (!strcmp(key, "split")) {
         c->opt_split = value != 0;
     } else if (!strcmp(key, "dynamic")) {

@@ -52,12 +52,12 @@ def test_golden_all_cases(searcher, gin, golden):
                                   {"score_mib": 0}, {"score_mib": 0, "tail_mode": 2}, {"bnd_mib": 1, "tail_mode": 2},
                                   {"bnd_mib": 1, "tail_mode": 2, "rows_per_wave": 16, "waves": 4}, {"bnd_mib": 1, "tail_mode": 2, "force_i32": 1},
                                   {"split": 0}, {"split": 0, "tail_mode": 2}, {"tail_mode": 2, "rows_per_wave": 12, "waves": 3},
-                                  # one launch per pass (the path before group-resident passes), with and without the two-stream split
-                                  {"resident": 0}, {"resident": 0, "tail_mode": 2}, {"resident": 0, "split": 0, "tail_mode": 2, "bnd_mib": 1},
-                                  # group-resident passes with a deep pipeline: most groups are shorter than 16 chunks and idle between passes
-                                  {"tail_mode": 2, "rows_per_wave": 8, "waves": 16}, {"tail_mode": 2, "rows_per_wave": 28, "waves": 8},
-                                  {"tail_mode": 2, "rows_per_wave": 36, "waves": 12}, {"f16": 0, "tail_mode": 2, "rows_per_wave": 16, "waves": 5},
-                                  {"force_i32": 1, "rows_per_wave": 16, "waves": 3}])
+                                  # group-resident passes (one launch per multi-pass query), also with a deep pipeline: most groups
+                                  # are then shorter than the pipeline and idle between their passes
+                                  {"resident": 1}, {"resident": 1, "tail_mode": 2}, {"resident": 1, "tail_mode": 1},
+                                  {"resident": 1, "tail_mode": 2, "rows_per_wave": 8, "waves": 16}, {"resident": 1, "tail_mode": 2, "rows_per_wave": 28, "waves": 8},
+                                  {"resident": 1, "tail_mode": 2, "rows_per_wave": 36, "waves": 12}, {"resident": 1, "f16": 0, "tail_mode": 2, "rows_per_wave": 16, "waves": 5},
+                                  {"resident": 1, "force_i32": 1, "rows_per_wave": 16, "waves": 3}, {"lane_room": 0}, {"lane_room": 1, "resident": 1}])
 def test_golden_kernel_variants(gin, golden, opts):
     q, pp, chunked = gin
     N = golden["search"]["n_sequences"]

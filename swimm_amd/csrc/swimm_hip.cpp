@@ -1123,6 +1123,10 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
             }
         }
+        // the next range's work lists need its geometry only: build them now, while the GPU aligns this range and
+        // before the host blocks in the next range's copies
+        if (streaming && ri + 1 < ranges.size())
+            for (uint32_t q = 0; q < qn; ++q) { DbPlan *dp = nullptr; if (plan_of(ri + 1, q, &dp)) return 1; }
     }
     if (streaming && sync_lengths(c)) return 1;    // the promotion re-runs stop every alignment at its true length
     const double t_issued = now_s();

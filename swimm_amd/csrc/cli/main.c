@@ -246,6 +246,35 @@ static uint64_t hybrid_split(const swimm_hip_api *api, const swimm_options *o, c
                 host_rate / 1e9, t_ctx, t_setup, up_rate / 1e9, gpu_rate / G / 1e9, host_cells, total);
     uint64_t n = 0, res = 0;
     while (n < db->count && (double)(res + db->lengths[n]) * Qrows <= host_cells) res += db->lengths[n++];
+    /* The host's rate depends on the sequence length (the sample above was the very shortest sequences), and most of its
+     * share's cells sit at the long end of the share: measure again there and size the share with that rate. */
+    if (n > 2 * sample) {
+        uint64_t w = 0, wres = 0;
+        while (w < n && wres * q->Q < 400000000ull) wres += db->lengths[n - 1 - w++];
+        w = w / vl * vl;
+        if (w >= vl) {
+            const uint64_t first = (n - w) / vl * vl;
+            uint64_t off = 0;
+            for (uint64_t i = 0; i < first; ++i) off += db->lengths[i];
+            wres = 0;
+            for (uint64_t i = first; i < first + w; ++i) wres += db->lengths[i];
+            rc = swimm_assemble_single_chunk(db->lengths + first, db->codes + off, w, o->vector_length, o->cpu_block_size, &sc);
+            if (rc) die_host(rc);
+            int32_t *s2 = (int32_t *)malloc(q->count * sizeof(int32_t));
+            int64_t *i2 = (int64_t *)malloc(q->count * sizeof(int64_t));
+            st.seconds = 0;
+            cpu_leg(o, &q0, submat, &sc, w, 1, s2, i2, &st);
+            free(s2); free(i2);
+            swimm_single_chunk_free(&sc);
+            const double rate2 = (double)wres * (double)q->Q / (st.seconds > 1e-6 ? st.seconds : 1e-6);
+            host_cells = (fixed + total / gpu_rate) / (1.0 / rate2 + 1.0 / gpu_rate);
+            if ((total - host_cells) / gpu_rate < t_upload) host_cells = (fixed + t_upload) * rate2;
+            if (host_cells > 0.5 * total) host_cells = 0.5 * total;
+            if (getenv("SWIMM_DEBUG")) fprintf(stderr, "swimm: hybrid probe: host at the far end of its share %.2f GCUPS -> %.3g cells\n", rate2 / 1e9, host_cells);
+            n = 0; res = 0;
+            while (n < db->count && (double)(res + db->lengths[n]) * Qrows <= host_cells) res += db->lengths[n++];
+        }
+    }
     n = n / 128 * 128;                               /* the GPU part keeps whole lane groups */
     return n >= vl && n < db->count ? n : 0;
 }

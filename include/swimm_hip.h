@@ -106,6 +106,12 @@ int swimm_hip_last_stats(swimm_hip_ctx *ctx, double *kernel_ms, uint64_t *cells,
  * rows of the query held per wavefront, wavefronts per workgroup, passes over the database. */
 int swimm_hip_last_plan(swimm_hip_ctx *ctx, uint32_t q, int *rows_per_wave, int *waves, int *passes);
 
+/* With the option "time_launches" set before the search: the sum of the durations of the search's pipeline-kernel
+ * launches, each measured by HIP events on the stream the launch ran on (what a kernel trace reports per dispatch;
+ * launches that share the chip on two streams each count with their own, longer, duration), and their number.
+ * Measurement aid for `roofline.kernel_ms` in bench.py; no reference counterpart. */
+int swimm_hip_last_launch_ms(swimm_hip_ctx *ctx, double *sum_ms, uint32_t *launches);
+
 /* Name of the dominant DP kernel of that plan, as the code object carries it and rocprofv3 lists it (demangled, e.g.
  * "void swimm::sw_pipe_kernel<24, 2, true>(swimm::PipeParams)"), so that a profile can be matched to a search
  * without guessing.  Measurement aid only (row (d) of SURVEY.md section 8); no reference counterpart. */
@@ -132,6 +138,7 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    streams, so that the end of every launch is covered by a kernel of the other query; 0 = one stream
  *   "split"          1 = default: a query of three or more passes runs the even- and odd-ranked groups as two kernels on two streams,
  *                    so that the end of one launch is covered by the other; 0 = one kernel per pass
+ *   "time_launches"  1 = bracket every pipeline launch with events (swimm_hip_last_launch_ms); default 0
  *   "lazy_upload"    0 = default: add_chunk / add_sequences copy the caller's buffers before they return; 1 = they only
  *                    record them and the next search streams the chunks in, copying and tiling chunk k+1 while chunk k
  *                    is being aligned (the double-buffered transfer of MICsearch.c:85-91) -- the buffers must then stay

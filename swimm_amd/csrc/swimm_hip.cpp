@@ -155,6 +155,11 @@ struct swimm_hip_ctx {
     int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
     int opt_resident = 0;               // 1: a multi-pass query runs as ONE launch whose workgroups take every group through all its passes back to back
     int opt_lane_room = -1;             // launch shapes must leave a lane-systolic wave its registers: -1 = when the database has a long-sequence tail, 0 never, 1 always
+    int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
+    std::vector<hipEvent_t> launch_ev;  // pairs (before, after), grown on demand
+    size_t launch_ev_used = 0;
+    double launch_ms_sum = 0;           // sum of the pipeline launches' own durations in the last search
+    uint32_t launch_ms_n = 0;
     int opt_alternate = 1;              // 1: the passes of consecutive multi-pass queries alternate between two streams
     int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
     int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
@@ -575,6 +580,22 @@ static bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &p
     return c->opt_dynamic && c->opt_split && qp.passes > 2 && n_segs == 1 && pl.n_wg >= 2 && pl.split_n[1] >= (uint32_t)pl.n_wg;
 }
 
+// measurement aid: the launch's own duration, on the stream it runs on (what a kernel trace reports per dispatch)
+static int timed_launch(swimm_hip_ctx *c, Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t st)
+{
+    if (!c->opt_time_launches) { HIP_TRY(launch_pipe(mode, T, W, n_wg, p, st)); return 0; }
+    while (c->launch_ev.size() < c->launch_ev_used + 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->launch_ev.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(c->launch_ev[c->launch_ev_used], st));
+    HIP_TRY(launch_pipe(mode, T, W, n_wg, p, st));
+    HIP_TRY(hipEventRecord(c->launch_ev[c->launch_ev_used + 1], st));
+    c->launch_ev_used += 2;
+    return 0;
+}
+
 // Group-resident passes (sw_pipe_kernel<.., RES = true>): one launch per multi-pass query, no launch boundary between passes
 // and no boundary rows shared between workgroups.
 static bool use_resident(const swimm_hip_ctx *c, const QueryPlan &qp) { return resident_for(c, qp.passes); }
@@ -601,7 +622,7 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
         p.first_pass = 1; p.last_pass = 0;
         p.out = out_row;
         p.err = c->d_err.p;
-        HIP_TRY(launch_pipe(mode, qp.T, qp.W, n_wg, p, st));
+        if (timed_launch(c, mode, qp.T, qp.W, n_wg, p, st)) return 1;
         c->launches++;
         c->cells += pl.total_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * qp.passes * (mode == Mode::I32 ? 64 : 128);
         return 0;
@@ -631,7 +652,7 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
                 p.last_pass = pass == qp.passes - 1;
                 p.out = out_row;
                 p.err = c->d_err.p;
-                HIP_TRY(launch_pipe(mode, qp.T, qp.W, (int)std::min<uint32_t>((uint32_t)n_half, pl.split_n[h]), p, h ? c->stream_b : c->stream));
+                if (timed_launch(c, mode, qp.T, qp.W, (int)std::min<uint32_t>((uint32_t)n_half, pl.split_n[h]), p, h ? c->stream_b : c->stream)) return 1;
                 c->launches++;
                 c->cells += pl.split_cols[h] * (uint64_t)(qp.W * qp.T) * (mode == Mode::I32 ? 64 : 128);
             }
@@ -672,7 +693,7 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
             p.stamps = c->d_stamps.p;
 #endif
             p.err = c->d_err.p;
-            HIP_TRY(launch_pipe(mode, qp.T, qp.W, n_wg, p, st));
+            if (timed_launch(c, mode, qp.T, qp.W, n_wg, p, st)) return 1;
 #ifdef SWIMM_STAMPS
             {
                 unsigned long long h[16 * 8];
@@ -1227,6 +1248,13 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->kernel_ms += ms;
+    for (size_t i = 0; i + 1 < c->launch_ev_used; i += 2) {
+        float lm = 0;
+        HIP_TRY(hipEventElapsedTime(&lm, c->launch_ev[i], c->launch_ev[i + 1]));
+        c->launch_ms_sum += lm;
+        c->launch_ms_n++;
+    }
+    c->launch_ev_used = 0;
     if (dbg)
         fprintf(stderr, "swimm_hip: queries %u..%u%s: plans + buffers %.3f s, launches issued %.3f s, ladder + drain %.3f s (device %.3f s)\n", qb, qe,
                 streaming ? " (streaming upload)" : "", t_sized - t_begin, t_issued - t_sized, now_s() - t_issued, ms * 1e-3);
@@ -1329,6 +1357,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->ev_tail3) (void)hipEventDestroy(c->ev_tail3);
     for (hipEvent_t e : c->ev_query) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->launch_ev) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
@@ -1447,7 +1476,7 @@ static uint32_t query_batch(const swimm_hip_ctx *c)
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->qm.size(), budget / per_query));
 }
 
-static void reset_stats(swimm_hip_ctx *c) { c->kernel_ms = 0; c->cells = 0; c->promoted = 0; c->promoted16 = 0; c->launches = 0; }
+static void reset_stats(swimm_hip_ctx *c) { c->kernel_ms = 0; c->cells = 0; c->promoted = 0; c->promoted16 = 0; c->launches = 0; c->launch_ms_sum = 0; c->launch_ms_n = 0; c->launch_ev_used = 0; }
 
 int swimm_hip_search(swimm_hip_ctx *c, int32_t *scores, uint64_t score_stride, double *work_time)
 {
@@ -1579,6 +1608,15 @@ int swimm_hip_last_plan(swimm_hip_ctx *c, uint32_t q, int *rows_per_wave, int *w
     return 0;
 }
 
+int swimm_hip_last_launch_ms(swimm_hip_ctx *c, double *sum_ms, uint32_t *launches)
+{
+    if (!c) return fail("swimm_hip_last_launch_ms: NULL ctx");
+    if (!c->opt_time_launches) return fail("swimm_hip_last_launch_ms: set the option \"time_launches\" before the search");
+    if (sum_ms) *sum_ms = c->launch_ms_sum;
+    if (launches) *launches = c->launch_ms_n;
+    return 0;
+}
+
 int swimm_hip_last_kernel_name(swimm_hip_ctx *c, uint32_t q, char *buf, size_t buf_len)
 {
     if (!c || !buf || buf_len == 0) return fail("swimm_hip_last_kernel_name: NULL argument");
@@ -1624,6 +1662,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         c->opt_lane_room = value;
     } else if (!strcmp(key, "resident")) {
         c->opt_resident = value != 0;
+    } else if (!strcmp(key, "time_launches")) {
+        c->opt_time_launches = value != 0;
     } else if (!strcmp(key, "alternate")) {
         c->opt_alternate = value != 0;
     } else if (!strcmp(key, "split")) {

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("SWIMM_HIP_LIB") or os.path.join(_HERE, "lib", "libswi
 ABI_SYMBOLS = (
     "swimm_hip_abi_version", "swimm_hip_last_error", "swimm_hip_device_count", "swimm_hip_create",
     "swimm_hip_destroy", "swimm_hip_set_queries", "swimm_hip_add_chunk", "swimm_hip_add_sequences", "swimm_hip_clear_db",
-    "swimm_hip_search", "swimm_hip_search_topr", "swimm_hip_last_stats", "swimm_hip_last_plan", "swimm_hip_last_kernel_name",
+    "swimm_hip_search", "swimm_hip_search_topr", "swimm_hip_last_stats", "swimm_hip_last_plan", "swimm_hip_last_kernel_name", "swimm_hip_last_launch_ms",
     "swimm_hip_set_option",
     "swimm_hip_search_chunks",
 )
@@ -159,6 +159,12 @@ class HipSearcher:
         t = C.c_int(); w = C.c_int(); p = C.c_int()
         _check(self._L.swimm_hip_last_plan(self._ctx, C.c_uint32(q), C.byref(t), C.byref(w), C.byref(p)))
         return {"rows_per_wave": t.value, "waves": w.value, "passes": p.value}
+
+    def last_launch_ms(self):
+        """(sum of the pipeline launches' own durations in ms, number of launches); needs set_option("time_launches", 1)"""
+        ms = C.c_double(); n = C.c_uint32()
+        _check(self._L.swimm_hip_last_launch_ms(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def last_kernel_name(self, q: int = 0) -> str:
         buf = C.create_string_buffer(256)

@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2")
     ap.add_argument("--scale", type=float, default=None, help="fraction of the configuration's database (default: c2 1.0, c5 0.25)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the first-search-after-a-cold-upload measurement (profiling runs: only the resident search's launches in the trace)")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--max-waves", type=int, default=0)
     ap.add_argument("--wgs-per-cu", type=int, default=0)
@@ -374,14 +375,16 @@ def main():
     all_ok, all_top_ok = bool(flags[0].item()), bool(flags[1].item())
 
     # ---- first search after a cold upload (the reference's workTime brackets the transfers, MICsearch.c:51,350) ----
-    searcher.clear_db()
-    searcher.set_option("lazy_upload", 1)        # chunks stream in while the search runs (what swimm_hip_search_chunks does)
-    barrier()
-    t0 = time.perf_counter()
-    upload()
-    exchange(*searcher.search_topr(TOP_R, n_valid)[:2])
-    barrier()
-    cold_s = time.perf_counter() - t0
+    cold_s = float("nan")
+    if not args.no_cold:
+        searcher.clear_db()
+        searcher.set_option("lazy_upload", 1)        # chunks stream in while the search runs (what swimm_hip_search_chunks does)
+        barrier()
+        t0 = time.perf_counter()
+        upload()
+        exchange(*searcher.search_topr(TOP_R, n_valid)[:2])
+        barrier()
+        cold_s = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([cold_s], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -447,7 +450,7 @@ def main():
                               "class_source": "VOP3P packed / 3-source ops issue over 4 cycles on gfx950; 4.40 measured in isolation with 4 waves per SIMD (profiles/r01_valu_issue_rates.txt)",
                               "kernel_only_gcups": round(kernel_gcups, 2), "padded_cells": cells_padded},
             "search_call_ms": round(float(np.mean(wts)) * 1e3, 4),
-            "value_incl_h2d": round(q_real * total_residues / cold_s / 1e9, 2),
+            "value_incl_h2d": None if args.no_cold else round(q_real * total_residues / cold_s / 1e9, 2),
             "value_incl_h2d_note": f"first search after a cold upload of the shard (pageable host memory, {'reference chunk layout' if args.workload == 'c2' else '.seq slabs'}; chunk k+1 copied and tiled while chunk k is aligned), {cold_s * 1e3:.1f} ms",
             "h2d_upload_s": round(t_up, 3), "datagen_s": round(t_gen, 2),
             "top1": [int(top_s[0][0]), int(top_i[0][0])],

@@ -29,6 +29,14 @@ struct Item {
     uint64_t bnd_off;    // first column of this item in the pass-boundary buffer
 };
 
+// group-resident launches: one query of the batch the launch serves
+struct QDesc {
+    uint32_t prof_off;      // first element of the query's profile in PipeParams::prof
+    uint32_t prof_stride;   // rows allocated per residue code
+    uint32_t passes;        // ceil(rows / (W * T))
+    uint32_t out_off;       // first element of the query's score row in PipeParams::out
+};
+
 struct PipeParams {
     const Item *items;
     const uint32_t *wg_first;   // static partition: [n_wg + 1] item ranges
@@ -42,9 +50,10 @@ struct PipeParams {
     uint32_t r0;                // first query row of this pass
     uint2 *bnd;                 // pass boundary rows (H,F per column per lane), updated in place
     int first_pass, last_pass;  // one pass per launch
-    uint32_t passes;            // > 1: group-resident passes -- every workgroup takes a group through all `passes` passes back to
-                                // back (dynamic queue only); bnd then holds bnd_wg_cols columns per workgroup, touched by it alone
-    uint32_t bnd_wg_cols;
+    const QDesc *qdesc;         // group-resident launches: the batch's queries (items are (group, query) pairs, n_items = groups x n_queries)
+    uint32_t n_queries;         // (qdesc != nullptr selects the group-resident kernel: every workgroup takes a group through all
+                                // the passes of an item's query back to back)
+    uint32_t bnd_wg_cols;       // group-resident launches: bnd holds this many columns per workgroup, touched by it alone
     int32_t *out;               // packed mode: score row of this query; int32 mode: out32
     int goe, ge;                // open+extend, extend
     uint32_t *err;              // watchdog word shared with the lane kernel

@@ -181,6 +181,16 @@ __device__ __forceinline__ Item load_item(const Item *items, uint32_t idx)
     return it;
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+static_assert(sizeof(QDesc) == 16, "QDesc is loaded as four dwords");
+__device__ __forceinline__ QDesc load_qdesc(const QDesc *q, uint32_t idx)
+{
+    const u32x4 r = *(const __attribute__((address_space(4))) u32x4 *)(uintptr_t)(q + idx);
+    QDesc d;
+    d.prof_off = r[0]; d.prof_stride = r[1]; d.passes = r[2]; d.out_off = r[3];
+    return d;
+}
+
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t x)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
@@ -287,16 +297,21 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 
     uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, out_slot = 0, n = 0, next_it = kNoItem;
     uint32_t pass = 0, len = 0;            // RES: pass of the current item; steps the item-pass occupies (>= nch)
-    int staged_pass = -1;                  // RES: which pass's rows this wave's strip of the LDS profile holds
-    // RES: the strip's profile rows of the NEXT pass are requested during the last chunk of the current item-pass, straight
+    // RES: an item is a (group, query) pair -- item id v = group rank * n_queries + (n_queries - 1 - query), queries longest
+    // first within a group -- so one launch takes a whole batch of queries that share the launch shape; a single multi-pass
+    // query is the batch of one.  Per query: where its profile lies, how many passes it needs, where its scores go.
+    uint32_t passes = 1, cur_q = 0, q_stride = RES ? 0 : p.prof_stride;
+    const int16_t *q_prof = p.prof;
+    int32_t *q_out = p.out;
+    int staged_win = -1;                   // RES: which (query << 16 | pass) window this wave's strip of the LDS profile holds
+    // RES: the strip's profile rows of the NEXT window are requested during the last chunk of the current item-pass, straight
     // into a per-wave landing area in LDS (global_load_lds: no registers), so that the switch itself is a handful of LDS
     // reads and writes.  (Fetching them at the switch stalled the wave for an L2 round trip and, through the step barrier,
     // the whole workgroup: W stalls per item-pass, -3 % on c2, -10 % with 16 waves.)
     constexpr int NPF = strip_stage_dwords(T) / 64;
     uint32_t *const stage = (uint32_t *)(total_lds + 4) + (size_t)k * strip_stage_dwords(T);
-    int pf_pass = -1;
-    const uint32_t passes = RES ? p.passes : 1u;
-    auto fetch_strip = [&](uint32_t ps) {
+    int pf_win = -1;
+    auto fetch_strip = [&](const int16_t *prof, uint32_t stride, uint32_t ps, int win) {
         const uint32_t row0 = ps * (uint32_t)(W * T) + (uint32_t)(k * T);
         int ln = lane;
         asm volatile("" : "+v"(ln));     // opaque: otherwise the per-lane addresses are hoisted out of the main loop and held in 2 x NPF registers
@@ -305,11 +320,12 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             int idx = ln + 64 * i;
             if (idx >= kCodes * (T / 2)) idx = 0;        // (landing slots past the strip's last dword are never read)
             const int d = idx / (T / 2), x = idx - d * (T / 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(p.prof + (size_t)d * p.prof_stride + row0 + 2 * x),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(prof + (size_t)d * stride + row0 + 2 * x),
                                              (__attribute__((address_space(3))) void *)(stage + 64 * i), 4, 0, 0);
         }
-        pf_pass = (int)ps;
+        pf_win = win;
     };
+    const uint32_t nq = RES ? p.n_queries : 1u;
     uint64_t bnd_off = 0;
     const uint8_t *dbp = nullptr;
     uint32_t nwa = 0, nwb = 0;     // residues of the wave's next chunk, loaded one step ahead
@@ -338,18 +354,26 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
         if (c >= 0 && it != kNoItem) {            // wave-uniform
             if (cc == 0) {                        // first chunk of a new item (RES: item-pass): reset the DP state
                 // the item is the same for the whole wave: one scalar load, descriptor in scalar registers
-                const Item iv = load_item(p.items, __builtin_amdgcn_readfirstlane(it));
+                const uint32_t vi = __builtin_amdgcn_readfirstlane(it);
+                const uint32_t gi = RES ? vi / nq : vi;
+                const Item iv = load_item(p.items, gi);
                 nch = iv.ncols / C; dbp = iv.db; seq0 = iv.seq0;
                 half = iv.half; out_slot = iv.out_slot;
                 bnd_off = RES ? (uint64_t)blockIdx.x * p.bnd_wg_cols : iv.bnd_off;
+                if (RES && pass == 0) {               // a new (group, query) item: the query's parameters, one scalar load
+                    cur_q = nq - 1 - (vi - gi * nq);
+                    const QDesc qd = load_qdesc(p.qdesc, cur_q);
+                    passes = qd.passes; q_prof = p.prof + qd.prof_off; q_stride = qd.prof_stride; q_out = p.out + qd.out_off;
+                }
                 len = (RES && pass + 1 < passes && nch < (uint32_t)W) ? (uint32_t)W : nch;
                 best = Ops::zero(); diag_top = Ops::zero();
 #pragma unroll
                 for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
-                if (RES && staged_pass != (int)pass) {
-                    // this wave's strip of the profile for this pass: rows pass*W*T + k*T .. + T of all 25 codes.  Only
-                    // this wave reads that part of the LDS profile, so nobody has to be waited for.
-                    if (pf_pass != (int)pass) fetch_strip(pass);       // (first item of the workgroup: nothing was requested ahead)
+                const int win = (int)((cur_q << 16) | pass);
+                if (RES && staged_win != win) {
+                    // this wave's strip of the profile for this window: rows pass*W*T + k*T .. + T of the query's 25 codes.
+                    // Only this wave reads that part of the LDS profile, so nobody has to be waited for.
+                    if (pf_win != win) fetch_strip(q_prof, q_stride, pass, win);   // (first item of the workgroup: nothing was requested ahead)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows have landed (an LDS-DMA counts as a vector-memory operation)
                     int ln = lane;
                     asm volatile("" : "+v"(ln));
@@ -364,16 +388,10 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         }
                         if (idx < kCodes * (T / 2)) *(uint32_t *)(prof_lds + d * PS + (k * TP + 2 * x) * 2) = v;
                     }
-                    staged_pass = (int)pass;
+                    staged_win = win;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
-            }
-            if (RES && cc + 1 == nch && passes > 1) {
-                // last chunk of this item-pass: request the rows of the pass that follows (the next pass of this group, or
-                // pass 0 of the next one); they arrive while this chunk is computed
-                const uint32_t np = pass + 1 < passes ? pass + 1 : 0u;
-                if ((int)np != staged_pass) fetch_strip(np);
             }
             if (!RES || cc < nch) {               // (RES: a short group idles here to the pipeline's depth between two passes)
             // database residues of this chunk: 4 columns of the lane's sequence(s).  They were requested one
@@ -406,10 +424,25 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         next_it = it + 1 < it_end ? it + 1 : kNoItem;
                     }
                     if (next_it != kNoItem) {
-                        const Item niv = load_item(p.items, next_it);
+                        const Item niv = load_item(p.items, RES ? next_it / nq : next_it);
                         ndb = niv.db; ncc = 0; nhalf = niv.half;
                     } else {
                         have_next = false;
+                    }
+                }
+                if (RES && cc + 1 == nch) {
+                    // last chunk of this item-pass: request the profile rows of the window that follows -- the next pass of this
+                    // item, or pass 0 of the next item's query; they arrive while this chunk is computed
+                    if (pass + 1 < passes) {
+                        const int nwin = (int)((cur_q << 16) | (pass + 1));
+                        if (nwin != staged_win) fetch_strip(q_prof, q_stride, pass + 1, nwin);
+                    } else if (next_it != kNoItem) {
+                        const uint32_t ng = next_it / nq, nqi = nq - 1 - (next_it - ng * nq);
+                        const int nwin = (int)(nqi << 16);
+                        if (nwin != staged_win) {
+                            const QDesc nqd = load_qdesc(p.qdesc, nqi);
+                            fetch_strip(p.prof + nqd.prof_off, nqd.prof_stride, 0, nwin);
+                        }
                     }
                 }
                 if (have_next) {
@@ -525,14 +558,14 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             if (scored) {   // item(-pass) finished: every strip contributes its best (CPUsearch.c:670-676)
                 if (M == 2) {
                     const v2h b2 = __builtin_bit_cast(v2h, Ops::bits(best));
-                    atomicMax(p.out + seq0 + lane, (int)(float)b2.x);
-                    atomicMax(p.out + seq0 + 64 + lane, (int)(float)b2.y);
+                    atomicMax(q_out + seq0 + lane, (int)(float)b2.x);
+                    atomicMax(q_out + seq0 + 64 + lane, (int)(float)b2.y);
                 } else if (PK) {
                     const v2s b2 = __builtin_bit_cast(v2s, Ops::bits(best));
-                    atomicMax(p.out + seq0 + lane, (int)b2.x);
-                    atomicMax(p.out + seq0 + 64 + lane, (int)b2.y);
+                    atomicMax(q_out + seq0 + lane, (int)b2.x);
+                    atomicMax(q_out + seq0 + 64 + lane, (int)b2.y);
                 } else {
-                    atomicMax(p.out + (size_t)out_slot * 64 + lane, (int)Ops::bits(best));
+                    atomicMax(q_out + (size_t)out_slot * 64 + lane, (int)Ops::bits(best));
                 }
             }
             if (++cc >= len) {
@@ -625,7 +658,7 @@ hipError_t launch_pipe(Mode mode, int T, int W, int n_wg, const PipeParams &p, h
     if (W < 1 || W > kMaxWaves || n_wg < 1 || !pipe_has_variant(mode, T)) return hipErrorInvalidValue;
     if (T > 28 && W > 12) return hipErrorInvalidValue;    // __launch_bounds__ of those instantiations
     const bool dyn = p.queue != nullptr;
-    if (p.passes > 1) return dyn ? launch_any<true, true>(mode, T, W, n_wg, p, s) : hipErrorInvalidValue;
+    if (p.qdesc != nullptr) return dyn && p.n_queries > 0 ? launch_any<true, true>(mode, T, W, n_wg, p, s) : hipErrorInvalidValue;
     return dyn ? launch_any<true, false>(mode, T, W, n_wg, p, s) : launch_any<false, false>(mode, T, W, n_wg, p, s);
 }
 

@@ -155,6 +155,8 @@ struct swimm_hip_ctx {
     int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
     int opt_resident = 0;               // 1: a multi-pass query runs as ONE launch whose workgroups take every group through all its passes back to back
     int opt_lane_room = -1;             // launch shapes must leave a lane-systolic wave its registers: -1 = when the database has a long-sequence tail, 0 never, 1 always
+    bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
+    DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
     int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
     std::vector<hipEvent_t> launch_ev;  // pairs (before, after), grown on demand
     size_t launch_ev_used = 0;
@@ -248,7 +250,7 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, bool resident, i
 }
 
 // a query of several passes runs the group-resident kernel (one launch) unless that is switched off
-bool resident_for(const swimm_hip_ctx *c, int passes) { return c->opt_dynamic && c->opt_resident && passes > 1; }
+bool resident_for(const swimm_hip_ctx *c, int passes) { (void)passes; return c->opt_dynamic && c->opt_resident && !c->streaming_now; }
 
 // a run of consecutive device groups that is searched as one unit: the whole resident database (work lists cached),
 // or one chunk of a database that is still streaming in
@@ -333,6 +335,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
         const int T = 8 + 4 * ti;
         if (c->opt_T && T != c->opt_T) continue;
         if (!pipe_has_variant(mode, T)) continue;
+        if (T == 28 && !c->opt_T && resident_for(c, 2)) continue;   // the group-resident 28-row kernel does not fit 128 VGPRs (16 spilled)
         int maxW = (T > 28) ? 12 : 16;        // __launch_bounds__ of the instantiations
         if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
         const int strips = std::max(1, (m + T - 1) / T);
@@ -602,31 +605,43 @@ static bool use_resident(const swimm_hip_ctx *c, const QueryPlan &qp) { return r
 // boundary scratch of that mode: per workgroup, the columns of the longest group of the list (64 lanes x 8 B each)
 static uint64_t resident_bnd_elems(const Plan &pl) { return pl.n_items ? (uint64_t)pl.n_wg * pl.queue_cols[0] * 64 : 0; }
 
+// One group-resident launch for a batch of queries that share the launch shape: the items are (group, query) pairs, every
+// workgroup takes an item through all the passes of its query back to back.  `qd` = the batch's entries in d_qdesc.
+int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl, const QDesc *qd, uint32_t nq, uint64_t pass_sum, uint32_t max_passes,
+                       hipStream_t st, DevBuf<uint2> &bnd)
+{
+    PipeParams p{};
+    p.prof = c->d_prof.p;
+    p.prof_stride = 0;
+    p.bnd = bnd.p;
+    p.goe = c->open_gap + c->extend_gap;
+    p.ge = c->extend_gap;
+    if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
+    if (bnd.cap < resident_bnd_elems(pl) && max_passes > 1) return fail("internal: boundary scratch too small");
+    const uint64_t n_virtual = (uint64_t)pl.n_items * nq;
+    if (n_virtual > 0xFFFFFFF0ull) return fail("group-resident batch of %u queries x %u groups exceeds 2^32 items", nq, pl.n_items);
+    p.items = pl.queue_items.p;
+    p.n_items = (uint32_t)n_virtual;
+    const int n_wg = (int)std::min<uint64_t>((uint64_t)pl.n_wg, n_virtual);
+    // every item-pass takes its chunks, or the pipeline's depth if it is shorter than that
+    p.max_steps = (uint32_t)std::min<uint64_t>((pl.total_chunks + (uint64_t)pl.n_items * kMaxWaves) * pass_sum + kMaxWaves + 1, 0x3ffffff0u);
+    p.queue = c->d_queue.p + c->queue_next++;
+    p.qdesc = qd;
+    p.n_queries = nq;
+    p.bnd_wg_cols = pl.queue_cols[0];
+    p.r0 = 0;
+    p.first_pass = 1; p.last_pass = 0;
+    p.out = c->d_scores.p;
+    p.err = c->d_err.p;
+    if (timed_launch(c, mode, T, W, n_wg, p, st)) return 1;
+    c->launches++;
+    c->cells += pl.total_chunks * kChunkCols * (uint64_t)(W * T) * pass_sum * (mode == Mode::I32 ? 64 : 128);
+    return 0;
+}
+
 // `st`: stream of the one-kernel-per-pass path (one-pass queries rotate over three streams)
 int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st, bool allow_split, DevBuf<uint2> &bnd)
 {
-    if (use_resident(c, qp)) {
-        PipeParams p{};
-        fill_common(c, qp, p, bnd.p);
-        if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
-        if (bnd.cap < resident_bnd_elems(pl)) return fail("internal: boundary scratch too small");
-        p.items = pl.queue_items.p;
-        p.n_items = pl.n_items;
-        const int n_wg = (int)std::min<uint32_t>((uint32_t)pl.n_wg, pl.n_items);
-        // every item-pass takes its chunks, or the pipeline's depth if it is shorter than that
-        p.max_steps = (uint32_t)std::min<uint64_t>((pl.total_chunks + (uint64_t)pl.n_items * kMaxWaves) * qp.passes + kMaxWaves + 1, 0x3ffffff0u);
-        p.queue = c->d_queue.p + c->queue_next++;
-        p.passes = (uint32_t)qp.passes;
-        p.bnd_wg_cols = pl.queue_cols[0];
-        p.r0 = 0;
-        p.first_pass = 1; p.last_pass = 0;
-        p.out = out_row;
-        p.err = c->d_err.p;
-        if (timed_launch(c, mode, qp.T, qp.W, n_wg, p, st)) return 1;
-        c->launches++;
-        c->cells += pl.total_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * qp.passes * (mode == Mode::I32 ? 64 : 128);
-        return 0;
-    }
     std::vector<std::pair<uint32_t, uint32_t>> segs;
     uint64_t seg_cols = pl.bnd_cols;
     if (c->opt_dynamic && qp.passes > 1) boundary_segments(c, pl, segs, &seg_cols);
@@ -904,6 +919,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     // database is one range with cached work lists.
     bool streaming = false;
     for (const ChunkRec &r : c->chunks) streaming = streaming || !r.uploaded;
+    c->streaming_now = streaming;
     std::vector<Range> ranges;
     std::vector<std::pair<size_t, size_t>> range_chunks;     // streaming: chunks [first, last) of every range
     if (streaming) {
@@ -994,7 +1010,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         }
     }
     c->last_plans.resize(c->qm.size());
-    for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = use_resident(c, qps[q]); c->last_plans[qb + q] = qps[q]; }
+    for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = use_resident(c, qps[q]) && !rotated[q]; c->last_plans[qb + q] = qps[q]; }
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
@@ -1072,7 +1088,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 tail_items = std::max<size_t>(tail_items, dp->tail.n);
             }
         HIP_TRY(c->d_bnd.reserve(need_bnd));
-        if (alternate) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
+        if (alternate || (c->opt_resident && !streaming)) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
@@ -1096,6 +1112,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->ev_query.push_back(e);
     }
+    std::map<std::pair<int, int>, std::vector<uint32_t>> batches;     // launch shape (T, W) -> queries whose bulk part runs group-resident
     for (size_t ri = 0; ri < ranges.size(); ++ri) {
         if (streaming) {
             for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci)
@@ -1136,13 +1153,54 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 }
             }
             DevBuf<uint2> *bnd = &c->d_bnd;
-            if (alternate && qps[q].passes > 1 && !rotated[q] && (multi_seen++ & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
+            if (alternate && qps[q].passes > 1 && !rotated[q] && !qps[q].resident && (multi_seen++ & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
             if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
+            if (qps[q].resident) {      // its bulk part goes into the group-resident launch of its shape, below
+                if (dp->have_main) batches[std::make_pair(qps[q].T, qps[q].W)].push_back(q);
+                else HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
+                HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
+                continue;
+            }
             if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row, bulk_stream, !streaming && !alternate, *bnd)) return 1;
             if (ri + 1 == ranges.size()) {
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
             }
+        }
+        // Group-resident launches: ONE launch per launch shape for all the batch's queries of that shape -- the items are
+        // (group, query) pairs, so even a small database gives every workgroup hundreds of them, the pipelines fill and
+        // drain once per batch, and no pass waits for the slowest workgroup of the one before it.  Shapes alternate
+        // between the two bulk streams.
+        if (!batches.empty()) {
+            std::vector<QDesc> qd_host;
+            for (auto &kv : batches) {
+                std::sort(kv.second.begin(), kv.second.end());          // ascending length: the kernel takes index nq - 1 (the longest) first
+                for (uint32_t q : kv.second) {
+                    if ((uint64_t)q * S > 0xFFFFFFFFull || qps[q].prof_off > 0xFFFFFFFFull) return fail("group-resident batch: score rows beyond 2^32 elements (lower score_mib)");
+                    qd_host.push_back(QDesc{(uint32_t)qps[q].prof_off, qps[q].mpad, (uint32_t)qps[q].passes, (uint32_t)((uint64_t)q * S)});
+                }
+            }
+            HIP_TRY(c->d_qdesc.reserve(qd_host.size()));
+            HIP_TRY(hipMemcpyAsync(c->d_qdesc.p, qd_host.data(), qd_host.size() * sizeof(QDesc), hipMemcpyHostToDevice, c->stream_up));
+            HIP_TRY(hipStreamSynchronize(c->stream_up));
+            size_t off = 0;
+            uint32_t bi = 0;
+            for (auto &kv : batches) {
+                const int T = kv.first.first, W = kv.first.second;
+                const uint32_t nqb = (uint32_t)kv.second.size();
+                DbPlan *dp = nullptr;
+                if (plan_of(ri, kv.second[0], &dp)) return 1;
+                uint64_t pass_sum = 0;
+                uint32_t max_p = 1;
+                for (uint32_t q : kv.second) { pass_sum += qps[q].passes; max_p = std::max<uint32_t>(max_p, qps[q].passes); }
+                hipStream_t st = (bi & 1) ? c->stream_b : c->stream;
+                DevBuf<uint2> &bnd = (bi & 1) ? c->d_bnd_b : c->d_bnd;
+                if (run_resident_batch(c, main_mode, T, W, dp->main, c->d_qdesc.p + off, nqb, pass_sum, max_p, st, bnd)) return 1;
+                for (uint32_t q : kv.second) HIP_TRY(hipEventRecord(c->ev_query[2 * q], st));
+                off += nqb;
+                ++bi;
+            }
+            batches.clear();
         }
         // the next range's work lists need its geometry only: build them now, while the GPU aligns this range and
         // before the host blocks in the next range's copies
@@ -1346,7 +1404,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     swimm_hip_clear_db(c);
-    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release();
+    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_qdesc.release();
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_a.release(); c->tail_scratch_b.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -70,6 +70,8 @@ def main():
     except OSError:
         pass
     cfg = line.get("config", {})
+    if not isinstance(cfg, dict):      # (a tool other than bench.py: its line names the configuration, no plan)
+        cfg = {"workload": str(cfg), "scale": line.get("scale", 1.0)}
     fetch, write = mean("FETCH_SIZE"), mean("WRITE_SIZE")
     if fetch is not None and write is not None:
         traffic = {

@@ -198,6 +198,39 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t x)
 }
 __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *q) { return (const uint8_t *)(uintptr_t)uniform_u64((uint64_t)(uintptr_t)q); }
 
+// (text shared by the two places where the pipeline kernel requests its next chunk; uses the kernel's local state)
+#define SWIMM_REQUEST_NEXT_CHUNK() \
+{ \
+                const uint8_t *ndb = dbp; \
+                uint32_t ncc = cc + 1, nhalf = half; \
+                have_next = true; \
+                if (RES && ncc == nch && pass + 1 < passes) { \
+                    ncc = 0; \
+                } else if (ncc == nch) { \
+ \
+                    if (DYN) { \
+                        next_it = __builtin_amdgcn_readfirstlane(seq[(n + 1) & (kSeqRing - 1)]); \
+                        if (k == 0 && next_it == kNoItem && lane == 0) *total_lds = c + 1; \
+                    } else { \
+                        next_it = it + 1 < it_end ? it + 1 : kNoItem; \
+                    } \
+                    if (next_it != kNoItem) { \
+                        const Item niv = load_item(p.items, RES ? next_it / nq : next_it); \
+                        ndb = niv.db; ncc = 0; nhalf = niv.half; \
+                    } else { \
+                        have_next = false; \
+                    } \
+                } \
+                if (have_next) { \
+                    if (PK) { \
+                        const unsigned long long w = *(const __attribute__((address_space(1))) unsigned long long *)(uintptr_t)(ndb + ((size_t)ncc * 64 + lane) * 8); \
+                        nwa = (uint32_t)w; nwb = (uint32_t)(w >> 32); \
+                    } else { \
+                        nwa = *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)(ndb + ((size_t)ncc * 64 + lane) * 8 + nhalf * 4); \
+                    } \
+                } \
+            }
+
 // M: 0 = packed int16, 1 = int32 (one sequence per lane), 2 = packed f16
 // DYN: false = the workgroup walks the item range the host gave it (static partition, longest first onto the
 //      least-loaded workgroup); true = wave 0 pulls the next item from a global cursor over the list sorted longest
@@ -320,8 +353,14 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             int idx = ln + 64 * i;
             if (idx >= kCodes * (T / 2)) idx = 0;        // (landing slots past the strip's last dword are never read)
             const int d = idx / (T / 2), x = idx - d * (T / 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(prof + (size_t)d * stride + row0 + 2 * x),
-                                             (__attribute__((address_space(3))) void *)(stage + 64 * i), 4, 0, 0);
+            // An LDS-DMA the compiler does not see: with the builtin, hipcc (ROCm 7.2) drains the vector-memory counter in
+            // front of every later LDS read and every barrier while the DMA might be in flight -- the step's database
+            // prefetch with it, every step (-9 % with 8-wave workgroups).  Hidden, the DMA is waited for where it is
+            // consumed (the explicit s_waitcnt vmcnt(0) at the window switch); an operation the compiler does not count
+            // can only make its own counted waits stricter, never weaker (the counter retires loads in order).
+            const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(stage + 64 * i);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                         :: "v"(prof + (size_t)d * stride + row0 + 2 * x), "s"(lds_addr) : "memory", "m0");
         }
         pf_win = win;
     };
@@ -365,7 +404,9 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                     const QDesc qd = load_qdesc(p.qdesc, cur_q);
                     passes = qd.passes; q_prof = p.prof + qd.prof_off; q_stride = qd.prof_stride; q_out = p.out + qd.out_off;
                 }
-                len = (RES && pass + 1 < passes && nch < (uint32_t)W) ? (uint32_t)W : nch;
+                // (wave 0 may read a column's boundary two steps after the last wave stored it at the earliest: the storing wave
+                // drains its stores at the top of its next step, below)
+                len = (RES && pass + 1 < passes && nch < (uint32_t)W + 1) ? (uint32_t)W + 1 : nch;
                 best = Ops::zero(); diag_top = Ops::zero();
 #pragma unroll
                 for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
@@ -406,53 +447,9 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 } else {
                     wa = *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)(dbp + ((size_t)cc * 64 + lane) * 8 + half * 4);
                 }
+                asm volatile("" : "+v"(wa), "+v"(wb));      // (first chunk of a workgroup's sequence only: wait for it here, not in the column loop)
             } else {
                 wa = nwa; wb = nwb;
-            }
-            {   // request the next chunk of this wave's stream (same item, or the first chunk of the next item)
-                const uint8_t *ndb = dbp;
-                uint32_t ncc = cc + 1, nhalf = half;
-                have_next = true;
-                if (RES && ncc == nch && pass + 1 < passes) {
-                    ncc = 0;                       // the same group again, next pass
-                } else if (ncc == nch) {
-                    // which item follows?  static: the next of the range; dynamic: the id wave 0 published in seq[]
-                    if (DYN) {
-                        next_it = __builtin_amdgcn_readfirstlane(seq[(n + 1) & (kSeqRing - 1)]);
-                        if (k == 0 && next_it == kNoItem && lane == 0) *total_lds = c + 1;   // this chunk is the last of the sequence
-                    } else {
-                        next_it = it + 1 < it_end ? it + 1 : kNoItem;
-                    }
-                    if (next_it != kNoItem) {
-                        const Item niv = load_item(p.items, RES ? next_it / nq : next_it);
-                        ndb = niv.db; ncc = 0; nhalf = niv.half;
-                    } else {
-                        have_next = false;
-                    }
-                }
-                if (RES && cc + 1 == nch) {
-                    // last chunk of this item-pass: request the profile rows of the window that follows -- the next pass of this
-                    // item, or pass 0 of the next item's query; they arrive while this chunk is computed
-                    if (pass + 1 < passes) {
-                        const int nwin = (int)((cur_q << 16) | (pass + 1));
-                        if (nwin != staged_win) fetch_strip(q_prof, q_stride, pass + 1, nwin);
-                    } else if (next_it != kNoItem) {
-                        const uint32_t ng = next_it / nq, nqi = nq - 1 - (next_it - ng * nq);
-                        const int nwin = (int)(nqi << 16);
-                        if (nwin != staged_win) {
-                            const QDesc nqd = load_qdesc(p.qdesc, nqi);
-                            fetch_strip(p.prof + nqd.prof_off, nqd.prof_stride, 0, nwin);
-                        }
-                    }
-                }
-                if (have_next) {
-                    if (PK) {
-                        const unsigned long long w = *(const __attribute__((address_space(1))) unsigned long long *)(uintptr_t)(ndb + ((size_t)ncc * 64 + lane) * 8);
-                        nwa = (uint32_t)w; nwb = (uint32_t)(w >> 32);
-                    } else {
-                        nwa = *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)(ndb + ((size_t)ncc * 64 + lane) * 8 + nhalf * 4);
-                    }
-                }
             }
             // top boundary of the strip for these columns: H of the row above, F entering row 0
             uint2 bin[C];
@@ -481,6 +478,15 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 #pragma unroll
                 for (int jj = 0; jj < C; ++jj) bin[jj] = src[jj * 64];
             }
+            if (RES && k == W - 1 && !last_pass) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous step's boundary stores have retired
+            // Request the next chunk of this wave's stream (same item, or the first chunk of the next item).  Which item follows?
+            // static: the next of the range; dynamic: the id wave 0 published in seq[] (a chunk that finds none is the last of the
+            // workgroup's sequence).  AFTER the boundary loads, so that waiting for those (older, and retired in order) leaves this
+            // one in flight; it is waited for at the END of the step (below), when it has long arrived, so that nothing in the
+            // column loop depends on a load: the next chunk's HBM latency is covered by this chunk's arithmetic.  (Round 1 issued
+            // the request first and used its register at once in the next step: the compiler put s_waitcnt vmcnt(0) in front of
+            // the column loop and every wave sat out its own prefetch, every step.)
+            SWIMM_REQUEST_NEXT_CHUNK();
             STAMP(tB);
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) {
@@ -553,6 +559,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 __builtin_amdgcn_sched_barrier(0);
             }
             STAMP(tC);
+            if (have_next) asm volatile("" : "+v"(nwa), "+v"(nwb));   // the next chunk's residues have arrived (requested before the column loop)
             }   // active step
             const bool scored = !RES ? cc + 1 == nch : cc + 1 == nch;
             if (scored) {   // item(-pass) finished: every strip contributes its best (CPUsearch.c:670-676)
@@ -577,6 +584,25 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                     ++n;
                     it = next_it;
                     pull = true;
+                }
+            }
+            if (RES && cc != 0 && cc + 1 == nch) {
+                // The coming step is the last chunk of this item-pass: request the profile rows of the window that follows -- the
+                // next pass of this item, or pass 0 of the next item's query (wave 0 published its id long ago) -- by LDS-DMA.
+                // At the END of the step: the wait hipcc puts in front of the next LDS read then finds nothing else young in flight.
+                if (pass + 1 < passes) {
+                    const int nwin = (int)((cur_q << 16) | (pass + 1));
+                    if (nwin != staged_win) fetch_strip(q_prof, q_stride, pass + 1, nwin);
+                } else {
+                    const uint32_t nv = DYN ? __builtin_amdgcn_readfirstlane(seq[(n + 1) & (kSeqRing - 1)]) : (it + 1 < it_end ? it + 1 : kNoItem);
+                    if (nv != kNoItem) {
+                        const uint32_t ng = nv / nq, nqi = nq - 1 - (nv - ng * nq);
+                        const int nwin = (int)(nqi << 16);
+                        if (nwin != staged_win) {
+                            const QDesc nqd = load_qdesc(p.qdesc, nqi);
+                            fetch_strip(p.prof + nqd.prof_off, nqd.prof_stride, 0, nwin);
+                        }
+                    }
                 }
             }
 #ifdef SWIMM_STAMPS

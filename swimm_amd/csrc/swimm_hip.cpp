@@ -624,7 +624,7 @@ int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl
     p.n_items = (uint32_t)n_virtual;
     const int n_wg = (int)std::min<uint64_t>((uint64_t)pl.n_wg, n_virtual);
     // every item-pass takes its chunks, or the pipeline's depth if it is shorter than that
-    p.max_steps = (uint32_t)std::min<uint64_t>((pl.total_chunks + (uint64_t)pl.n_items * kMaxWaves) * pass_sum + kMaxWaves + 1, 0x3ffffff0u);
+    p.max_steps = (uint32_t)std::min<uint64_t>((pl.total_chunks + (uint64_t)pl.n_items * (kMaxWaves + 1)) * pass_sum + kMaxWaves + 1, 0x3ffffff0u);
     p.queue = c->d_queue.p + c->queue_next++;
     p.qdesc = qd;
     p.n_queries = nq;

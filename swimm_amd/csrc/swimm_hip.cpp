@@ -153,8 +153,9 @@ struct swimm_hip_ctx {
     int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
     int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
     int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
-    int opt_resident = 0;               // 1: a multi-pass query runs as ONE launch whose workgroups take every group through all its passes back to back
+    int opt_resident = -1;              // group-resident batch launches: -1 = when the batch has two or more queries that are not rotated, 0 never, 1 always
     int opt_lane_room = -1;             // launch shapes must leave a lane-systolic wave its registers: -1 = when the database has a long-sequence tail, 0 never, 1 always
+    bool batch_now = false;             // the search in progress runs its non-rotated queries as group-resident batch launches
     bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
     DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
     int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
@@ -250,7 +251,7 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, bool resident, i
 }
 
 // a query of several passes runs the group-resident kernel (one launch) unless that is switched off
-bool resident_for(const swimm_hip_ctx *c, int passes) { (void)passes; return c->opt_dynamic && c->opt_resident && !c->streaming_now; }
+bool resident_for(const swimm_hip_ctx *c, int passes) { (void)passes; return c->batch_now; }
 
 // a run of consecutive device groups that is searched as one unit: the whole resident database (work lists cached),
 // or one chunk of a database that is still streaming in
@@ -366,6 +367,32 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
     // (no admissible shape leaves a lane-systolic wave its registers, e.g. under a max_waves cap: the tail then shares)
     if (best_cost < 0 && room_for_lane_waves) return choose_plan(c, mode, m, false, overlapped, out);
     if (best_cost < 0) { fail("no kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W); return 1; }
+    return 0;
+}
+
+// One launch shape for a whole batch of queries (group-resident launches take all queries of one shape in one launch): the
+// 4-wave shapes only -- measured (profiles/r02_ab_batch.txt), the group-resident kernel equals the per-pass kernel with 4-wave
+// workgroups and loses 9 % with 8 -- and the rows per wave that waste the fewest padded rows over the batch at that shape's rate.
+int choose_batch_shape(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, const std::vector<uint8_t> &rotated, uint32_t qn, bool room_for_lane_waves, int *T_out, int *W_out)
+{
+    double best = -1;
+    for (int ti = 7; ti >= 0; --ti) {
+        const int T = 8 + 4 * ti;
+        if (c->opt_T && T != c->opt_T) continue;
+        if (!pipe_has_variant(mode, T)) continue;
+        if (T == 28 && !c->opt_T) continue;                       // the group-resident 28-row kernel does not fit 128 VGPRs
+        const int W = c->opt_W > 0 ? std::min(c->opt_W, T > 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
+        int per_cu = 1, regs = 0;
+        if (wgs_per_cu(c, mode, T, W, true, &per_cu) || kernel_regs(c, mode, T, true, &regs)) return 1;
+        if (room_for_lane_waves && !c->opt_T && ((regs + 7) / 8 * 8) * ((per_cu * W + 3) / 4) > 512 - 80) continue;
+        double rows = 0;
+        for (uint32_t q = 0; q < qn; ++q)
+            if (!rotated[q]) rows += (double)((qm[q] + T * W - 1) / (T * W)) * T * W;
+        const double cost = rows / kShapeGcups[ti][W - 1];
+        if (best < 0 || cost < best) { best = cost; *T_out = T; *W_out = W; }
+    }
+    if (best < 0 && room_for_lane_waves) return choose_batch_shape(c, mode, qm, rotated, qn, false, T_out, W_out);
+    if (best < 0) return fail("no group-resident kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W);
     return 0;
 }
 
@@ -601,7 +628,6 @@ static int timed_launch(swimm_hip_ctx *c, Mode mode, int T, int W, int n_wg, con
 
 // Group-resident passes (sw_pipe_kernel<.., RES = true>): one launch per multi-pass query, no launch boundary between passes
 // and no boundary rows shared between workgroups.
-static bool use_resident(const swimm_hip_ctx *c, const QueryPlan &qp) { return resident_for(c, qp.passes); }
 // boundary scratch of that mode: per workgroup, the columns of the longest group of the list (64 lanes x 8 B each)
 static uint64_t resident_bnd_elems(const Plan &pl) { return pl.n_items ? (uint64_t)pl.n_wg * pl.queue_cols[0] * 64 : 0; }
 
@@ -633,7 +659,26 @@ int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl
     p.first_pass = 1; p.last_pass = 0;
     p.out = c->d_scores.p;
     p.err = c->d_err.p;
+#ifdef SWIMM_STAMPS
+    HIP_TRY(c->d_stamps.reserve(16 * 8 + 3072));
+    HIP_TRY(hipMemsetAsync(c->d_stamps.p, 0, 16 * 8 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->d_stamps.p + 15 * 8 + 2, 0xff, sizeof(unsigned long long), st));   // min slot
+    p.stamps = c->d_stamps.p;
+#endif
     if (timed_launch(c, mode, T, W, n_wg, p, st)) return 1;
+#ifdef SWIMM_STAMPS
+    {
+        unsigned long long h[16 * 8];
+        HIP_TRY(hipMemcpyAsync(h, c->d_stamps.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int w = 0; w < W; ++w)
+            fprintf(stderr, "stamps (resident batch of %u) wave %2d: load/wait %8.0f  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active of %llu steps per wg)\n", nq,
+                    w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4],
+                    (double)h[w * 8 + 3] / h[w * 8 + 4], h[w * 8 + 4] / n_wg, h[w * 8 + 5] / n_wg);
+        fprintf(stderr, "stamps: workgroup run time mean %.1f us, longest %.1f us; first start to last end %.1f us (%llu workgroups)\n",
+                (double)h[15 * 8 + 0] / h[15 * 8 + 4] / 100.0, (double)h[15 * 8 + 1] / 100.0, (double)(h[15 * 8 + 3] - h[15 * 8 + 2]) / 100.0, h[15 * 8 + 4]);
+    }
+#endif
     c->launches++;
     c->cells += pl.total_chunks * kChunkCols * (uint64_t)(W * T) * pass_sum * (mode == Mode::I32 ? 64 : 128);
     return 0;
@@ -979,15 +1024,37 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     const bool many_short = n_short >= 8 && !streaming;
     const bool rotate = many_short && (double)longest_cols <= 2.0 * (double)c->total_cols / c->num_cu;
     size_t prof_elems = 0;
+    // Group-resident batch launches (option "resident"): the queries that are not rotated share ONE launch shape and run as one
+    // launch whose items are (group, query) pairs.
+    c->batch_now = false;
+    {
+        uint32_t non_rot = 0;
+        for (uint32_t q = 0; q < qn; ++q) non_rot += !(rotate && qm[q] <= 64 * kLaneRows);
+        c->batch_now = !streaming && c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && non_rot >= 2));
+    }
     for (uint32_t q = 0; q < qn; ++q) {
         // Eight or more short queries in the batch: those that fit one pass run whole -- every group through the
         // pipeline kernel, no tail kernel -- on three streams in rotation (below); a long sequence's serial chain,
         // which bounds a lone short query, is then covered by the neighbours' work.
         rotated[q] = 0;
         if (rotate && qm[q] <= 64 * kLaneRows) {
+            c->batch_now = false;                 // (rotated queries run the per-pass kernel: plan them with its registers)
             rotated[q] = choose_plan(c, main_mode, qm[q], false, true, &qps[q]) == 0;   // fails when no one-pass shape exists
         }
-        if (!rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;
+    }
+    {
+        uint32_t non_rot = 0;
+        for (uint32_t q = 0; q < qn; ++q) non_rot += !rotated[q];
+        c->batch_now = !streaming && c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && non_rot >= 2)) && non_rot > 0;
+    }
+    int batch_T = 0, batch_W = 0;
+    if (c->batch_now && choose_batch_shape(c, main_mode, qm, rotated, qn, lane_room, &batch_T, &batch_W)) return 1;
+    for (uint32_t q = 0; q < qn; ++q) {
+        if (!rotated[q] && c->batch_now) {
+            const int strips = std::max(1, (qm[q] + batch_T - 1) / batch_T);
+            qps[q].T = batch_T; qps[q].W = batch_W; qps[q].passes = (strips + batch_W - 1) / batch_W;
+            qps[q].mpad = (uint32_t)(qps[q].passes * batch_W * batch_T);
+        } else if (!rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;
         if (dbg)
             fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
         const uint32_t lane_rows = (uint32_t)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
@@ -1010,7 +1077,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         }
     }
     c->last_plans.resize(c->qm.size());
-    for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = use_resident(c, qps[q]) && !rotated[q]; c->last_plans[qb + q] = qps[q]; }
+    for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = c->batch_now && !rotated[q]; c->last_plans[qb + q] = qps[q]; }
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
@@ -1019,7 +1086,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     // the work lists of a (range, launch shape): cached for the resident database, temporary for a streaming chunk
     auto plan_of = [&](size_t ri, uint32_t q, DbPlan **out) -> int {
         int per_cu = 1;
-        if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, resident_for(c, qps[q].passes), &per_cu)) return 1;
+        if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, c->batch_now && !rotated[q], &per_cu)) return 1;
         const int n_wg = n_workgroups(c, per_cu);
         if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0, out);
         auto it = stream_plans[ri].find(n_wg);
@@ -1059,9 +1126,9 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 for (uint32_t q = 0; q < qn; ++q) {
                     if (qps[q].passes <= 1) { launch_total += 2; continue; }
                     int per_cu = 1;
-                    if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, resident_for(c, qps[q].passes), &per_cu)) return 1;
+                    if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, c->batch_now && !rotated[q], &per_cu)) return 1;
                     const uint64_t cols = ranges[ri].cols * (main_mode == Mode::I32 ? 2 : 1);
-                    if (use_resident(c, qps[q])) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_main * 64);
+                    if (qps[q].resident) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_main * 64);
                     else need_bnd = std::max<uint64_t>(need_bnd, std::min<uint64_t>(cols, std::max<uint64_t>(budget, longest_main)) * 64);
                     launch_total += (size_t)qps[q].passes * (size_t)(cols / std::max<uint64_t>(budget, 1) + 2);
                 }
@@ -1072,7 +1139,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 DbPlan *dp = nullptr;
                 if (plan_of(ri, q, &dp)) return 1;
                 size_t nsegs = 1;
-                if (use_resident(c, qps[q]) && dp->have_main) {
+                if (qps[q].resident && dp->have_main) {
                     need_bnd = std::max<uint64_t>(need_bnd, resident_bnd_elems(dp->main));
                 } else if (qps[q].passes > 1 && dp->have_main) {
                     uint64_t cols = dp->main.bnd_cols;
@@ -1719,7 +1786,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         if (value < -1 || value > 1) return fail("lane_room must be -1 (auto), 0 or 1");
         c->opt_lane_room = value;
     } else if (!strcmp(key, "resident")) {
-        c->opt_resident = value != 0;
+        if (value < -1 || value > 1) return fail("resident must be -1 (auto), 0 or 1");
+        c->opt_resident = value;
     } else if (!strcmp(key, "time_launches")) {
         c->opt_time_launches = value != 0;
     } else if (!strcmp(key, "alternate")) {

@@ -66,7 +66,7 @@ def test_c4_long_query_envnr_shape():
     with hip_backend.HipSearcher(0) as s:
         s.set_queries(w["a"], w["m"], w["disp"], matrix(w["matrix"]), 10, 2)
         _load(s, chunks.chunks)
-        got, _ = s.search(chunks.vc * 128)
+        got, _ = s.search(chunks.vc * 128)         # one query: one launch per pass (group-resident batches need two queries or the option)
         plan = s.last_plan(0)
         launches = s.last_stats()["launches"]
         # the same recurrence cut differently: group-resident passes (one launch, every workgroup takes a group through all
@@ -110,6 +110,7 @@ def test_c5_envnr_pam250_eight_way_shard(monkeypatch):
             s.set_option("wg_limit", 4)
             s.set_option("tail_mode", 2)
             if d % 2:    # odd devices: one launch per pass, the boundary rows through HBM in two runs; even: group-resident passes
+                s.set_option("resident", 0)
                 s.set_option("bnd_mib", max(1, int(cols * 512 * 0.55) >> 20))
             else:
                 s.set_option("resident", 1)

@@ -49,9 +49,12 @@ def test_golden_all_cases(searcher, gin, golden):
                                   {"dynamic": 0}, {"dynamic": 0, "tail_mode": 2, "f16": 0}, {"dynamic": 0, "tail_mode": 2, "max_waves": 3},
                                   {"rows_per_wave": 8}, {"rows_per_wave": 12, "tail_mode": 2}, {"rows_per_wave": 20}, {"rows_per_wave": 28, "waves": 4},
                                   {"rows_per_wave": 36}, {"rows_per_wave": 36, "waves": 3, "tail_mode": 2}, {"rows_per_wave": 20, "waves": 7},
-                                  {"score_mib": 0}, {"score_mib": 0, "tail_mode": 2}, {"bnd_mib": 1, "tail_mode": 2},
-                                  {"bnd_mib": 1, "tail_mode": 2, "rows_per_wave": 16, "waves": 4}, {"bnd_mib": 1, "tail_mode": 2, "force_i32": 1},
-                                  {"split": 0}, {"split": 0, "tail_mode": 2}, {"tail_mode": 2, "rows_per_wave": 12, "waves": 3},
+                                  {"score_mib": 0}, {"score_mib": 0, "tail_mode": 2}, {"resident": 0, "bnd_mib": 1, "tail_mode": 2},
+                                  {"resident": 0, "bnd_mib": 1, "tail_mode": 2, "rows_per_wave": 16, "waves": 4}, {"resident": 0, "bnd_mib": 1, "tail_mode": 2, "force_i32": 1},
+                                  {"resident": 0, "split": 0}, {"resident": 0, "split": 0, "tail_mode": 2}, {"tail_mode": 2, "rows_per_wave": 12, "waves": 3},
+                                  # one launch per query and pass (the default for a single query), alternating streams or not
+                                  {"resident": 0}, {"resident": 0, "tail_mode": 2}, {"resident": 0, "alternate": 0}, {"resident": 0, "alternate": 0, "tail_mode": 1},
+                                  {"resident": 0, "rows_per_wave": 28, "waves": 8, "tail_mode": 2},
                                   # group-resident passes (one launch per multi-pass query), also with a deep pipeline: most groups
                                   # are then shorter than the pipeline and idle between their passes
                                   {"resident": 1}, {"resident": 1, "tail_mode": 2}, {"resident": 1, "tail_mode": 1},

@@ -195,7 +195,7 @@ static uint64_t hybrid_split(const swimm_hip_api *api, const swimm_options *o, c
         return n < db->count ? n : 0;
     }
     uint64_t sample = 0, sample_res = 0;
-    while (sample < db->count && sample_res * q->Q < 400000000ull) sample_res += db->lengths[sample++];
+    while (sample < db->count && sample_res * q->Q < 2000000000ull) sample_res += db->lengths[sample++];
     sample = (sample + vl - 1) / vl * vl;
     if (sample == 0 || sample >= db->count) return 0;
     swimm_queries q0 = *q;                          /* the whole batch: the host's rate depends on the query length */
@@ -264,7 +264,7 @@ static uint64_t hybrid_split(const swimm_hip_api *api, const swimm_options *o, c
      * share's cells sit at the long end of the share: measure again there and size the share with that rate. */
     if (n > 2 * sample) {
         uint64_t w = 0, wres = 0;
-        while (w < n && wres * q->Q < 400000000ull) wres += db->lengths[n - 1 - w++];
+        while (w < n && wres * q->Q < 2000000000ull) wres += db->lengths[n - 1 - w++];
         w = w / vl * vl;
         if (w >= vl) {
             const uint64_t first = (n - w) / vl * vl;

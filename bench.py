@@ -404,7 +404,7 @@ def main():
         # launched on and reports their sum and number (two launches that share the chip on two streams each count with
         # their own, longer, duration -- exactly what a kernel trace lists per dispatch).
         pipe_launches = max(1, int(round(np.mean([n for _, n in launch_ms]))))
-        per_launch_ms = float(np.mean([ms_ / max(n, 1) for ms_, n in launch_ms]))
+        per_launch_ms = max(float(np.mean([ms_ / max(n, 1) for ms_, n in launch_ms])), 1e-6)   # (a shard so small that every group runs on the lane-systolic kernel has no pipeline launch)
         single_kernel = nq == 1                                    # one query = one kernel instantiation: per-launch figures are meaningful
         achieved = (alg_bytes / pipe_launches) / (per_launch_ms * 1e-3) / 1e9 if single_kernel else alg_bytes / (k_ms_mean * 1e-3) / 1e9
         plan_key = {"rows_per_wave": plans[-1]["rows_per_wave"], "waves": plans[-1]["waves"], "passes": plans[-1]["passes"]}

@@ -263,8 +263,12 @@ static uint64_t hybrid_split(const swimm_hip_api *api, const swimm_options *o, c
     /* The host's rate depends on the sequence length (the sample above was the very shortest sequences), and most of its
      * share's cells sit at the long end of the share: measure again there and size the share with that rate. */
     if (n > 2 * sample) {
+        /* long enough (about 0.4 s at the first probe's rate) to see the rate the host SUSTAINS: on the test box a burst of
+         * 10 ms ran 3.5x faster than a second of the same work (shared host, CPU quota), and the share is sized for a leg
+         * that lasts as long as the GPUs' */
+        const double target_cells = 0.4 * host_rate;
         uint64_t w = 0, wres = 0;
-        while (w < n && wres * q->Q < 2000000000ull) wres += db->lengths[n - 1 - w++];
+        while (w < n && (double)wres * (double)q->Q < target_cells) wres += db->lengths[n - 1 - w++];
         w = w / vl * vl;
         if (w >= vl) {
             const uint64_t first = (n - w) / vl * vl;

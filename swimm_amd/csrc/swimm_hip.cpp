@@ -1048,7 +1048,10 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         c->batch_now = !streaming && c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && non_rot >= 2)) && non_rot > 0;
     }
     int batch_T = 0, batch_W = 0;
-    if (c->batch_now && choose_batch_shape(c, main_mode, qm, rotated, qn, lane_room, &batch_T, &batch_W)) return 1;
+    // (no register room is reserved for the lane-systolic waves here: among the 4-wave shapes only the 8-row one would pass that
+    // filter, at 6 000 instead of 8 400 GCUPS; the tail kernels are launched first and get their slots, the batch launch's
+    // workgroups that do not fit beside them start when they are done)
+    if (c->batch_now && choose_batch_shape(c, main_mode, qm, rotated, qn, false, &batch_T, &batch_W)) return 1;
     for (uint32_t q = 0; q < qn; ++q) {
         if (!rotated[q] && c->batch_now) {
             const int strips = std::max(1, (qm[q] + batch_T - 1) / batch_T);

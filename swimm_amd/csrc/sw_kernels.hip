@@ -359,8 +359,9 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             // consumed (the explicit s_waitcnt vmcnt(0) at the window switch); an operation the compiler does not count
             // can only make its own counted waits stricter, never weaker (the counter retires loads in order).
             const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(stage + 64 * i);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                         :: "v"(prof + (size_t)d * stride + row0 + 2 * x), "s"(lds_addr) : "memory", "m0");
+            uint32_t m0_saved;      // (M0 is a reserved register for the compiler: put back what it held)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "v"(prof + (size_t)d * stride + row0 + 2 * x), "s"(lds_addr) : "memory");
         }
         pf_win = win;
     };

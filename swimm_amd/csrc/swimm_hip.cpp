@@ -389,6 +389,7 @@ int choose_batch_shape(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, const st
         for (uint32_t q = 0; q < qn; ++q)
             if (!rotated[q]) rows += (double)((qm[q] + T * W - 1) / (T * W)) * T * W;
         const double cost = rows / kShapeGcups[ti][W - 1];
+        if (getenv("SWIMM_HIP_DEBUG")) fprintf(stderr, "swimm_hip: batch shape %d x %d: %.0f padded rows / %.0f GCUPS = %.3f (%d workgroups per CU, %d VGPRs)\n", W, T, rows, (double)kShapeGcups[ti][W - 1], cost, per_cu, regs);
         if (best < 0 || cost < best) { best = cost; *T_out = T; *W_out = W; }
     }
     if (best < 0 && room_for_lane_waves) return choose_batch_shape(c, mode, qm, rotated, qn, false, T_out, W_out);

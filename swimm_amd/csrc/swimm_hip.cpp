@@ -1053,6 +1053,24 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     // filter, at 6 000 instead of 8 400 GCUPS; the tail kernels are launched first and get their slots, the batch launch's
     // workgroups that do not fit beside them start when they are done)
     if (c->batch_now && choose_batch_shape(c, main_mode, qm, rotated, qn, false, &batch_T, &batch_W)) return 1;
+    if (c->batch_now) {
+        // A batch launch is one persistent kernel for the whole batch: lane-systolic tail kernels launched beside it would
+        // find no free slot until it ends (measured: c3 -16 %, a 1e8-residue database -25 %).  So a batch takes EVERY group
+        // through the pipeline kernel -- which is fine as long as the longest item (longest group x the passes of the
+        // longest query) is small beside a workgroup's share of the batch; otherwise (c3: a 35 000-residue sequence is 2.3
+        // shares) the batch is not formed and the queries run one launch per pass beside their tail kernels.
+        double pass_sum = 0;
+        uint32_t max_passes = 1;
+        for (uint32_t q = 0; q < qn; ++q)
+            if (!rotated[q]) {
+                const uint32_t ps = (uint32_t)(((qm[q] + batch_T - 1) / batch_T + batch_W - 1) / batch_W);
+                pass_sum += ps; max_passes = std::max(max_passes, ps);
+            }
+        int per_cu = 1;
+        if (wgs_per_cu(c, main_mode, batch_T, batch_W, true, &per_cu)) return 1;
+        const double share = pass_sum * (double)c->total_cols / n_workgroups(c, per_cu);
+        if (c->opt_resident < 0 && (double)longest_cols * max_passes > 0.25 * share) c->batch_now = false;
+    }
     for (uint32_t q = 0; q < qn; ++q) {
         if (!rotated[q] && c->batch_now) {
             const int strips = std::max(1, (qm[q] + batch_T - 1) / batch_T);
@@ -1092,7 +1110,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         int per_cu = 1;
         if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, c->batch_now && !rotated[q], &per_cu)) return 1;
         const int n_wg = n_workgroups(c, per_cu);
-        if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0, out);
+        if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0 || qps[q].resident, out);
         auto it = stream_plans[ri].find(n_wg);
         if (it == stream_plans[ri].end()) {
             DbPlan &dp = stream_plans[ri][n_wg];
@@ -1225,8 +1243,8 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             }
             DevBuf<uint2> *bnd = &c->d_bnd;
             if (alternate && qps[q].passes > 1 && !rotated[q] && !qps[q].resident && (multi_seen++ & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
-            if (run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
-            if (qps[q].resident) {      // its bulk part goes into the group-resident launch of its shape, below
+            if (!qps[q].resident && run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
+            if (qps[q].resident) {      // every group goes into the group-resident launch of its shape, below
                 if (dp->have_main) batches[std::make_pair(qps[q].T, qps[q].W)].push_back(q);
                 else HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));

@@ -1070,6 +1070,10 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         if (wgs_per_cu(c, main_mode, batch_T, batch_W, true, &per_cu)) return 1;
         const double share = pass_sum * (double)c->total_cols / n_workgroups(c, per_cu);
         if (c->opt_resident < 0 && (double)longest_cols * max_passes > 0.25 * share) c->batch_now = false;
+        // ... and it pays on a database that is small for the chip: with few groups per workgroup every per-pass launch fills and
+        // drains its pipelines for two or three items and ends unbalanced (1e8 residues: +13-15 %); with dozens of groups per
+        // workgroup the per-pass launches with per-query shapes are 2-3 % ahead (c5 at 10 %: 8 470 vs 8 250 GCUPS)
+        if (c->opt_resident < 0 && c->groups.size() >= (size_t)16 * n_workgroups(c, per_cu)) c->batch_now = false;
     }
     for (uint32_t q = 0; q < qn; ++q) {
         if (!rotated[q] && c->batch_now) {

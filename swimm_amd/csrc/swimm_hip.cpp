@@ -1031,7 +1031,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     {
         uint32_t non_rot = 0;
         for (uint32_t q = 0; q < qn; ++q) non_rot += !(rotate && qm[q] <= 64 * kLaneRows);
-        c->batch_now = !streaming && c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && non_rot >= 2));
+        c->batch_now = c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && (non_rot >= 2 || streaming)));
     }
     for (uint32_t q = 0; q < qn; ++q) {
         // Eight or more short queries in the batch: those that fit one pass run whole -- every group through the
@@ -1046,7 +1046,9 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     {
         uint32_t non_rot = 0;
         for (uint32_t q = 0; q < qn; ++q) non_rot += !rotated[q];
-        c->batch_now = !streaming && c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && non_rot >= 2)) && non_rot > 0;
+        // (a database that is streaming in is aligned range by range: there even a single query runs group-resident, one launch
+        // per range instead of one per range and pass)
+        c->batch_now = c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && (non_rot >= 2 || streaming))) && non_rot > 0;
     }
     int batch_T = 0, batch_W = 0;
     // (no register room is reserved for the lane-systolic waves here: among the 4-wave shapes only the 8-row one would pass that
@@ -1073,7 +1075,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         // ... and it pays on a database that is small for the chip: with few groups per workgroup every per-pass launch fills and
         // drains its pipelines for two or three items and ends unbalanced (1e8 residues: +13-15 %); with dozens of groups per
         // workgroup the per-pass launches with per-query shapes are 2-3 % ahead (c5 at 10 %: 8 470 vs 8 250 GCUPS)
-        if (c->opt_resident < 0 && c->groups.size() >= (size_t)16 * n_workgroups(c, per_cu)) c->batch_now = false;
+        if (c->opt_resident < 0 && !streaming && c->groups.size() >= (size_t)16 * n_workgroups(c, per_cu)) c->batch_now = false;
     }
     for (uint32_t q = 0; q < qn; ++q) {
         if (!rotated[q] && c->batch_now) {
@@ -1120,7 +1122,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             DbPlan &dp = stream_plans[ri][n_wg];
             bool exact = true;
             for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[ci].lens_known;
-            if (make_db_plan(c, main_mode, n_wg, false, ranges[ri], exact, dp)) return 1;
+            if (make_db_plan(c, main_mode, n_wg, qps[q].resident, ranges[ri], exact, dp)) return 1;
             *out = &dp;
         } else {
             *out = &it->second;
@@ -1142,8 +1144,9 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             for (size_t ri = 0; ri < ranges.size(); ++ri) {
                 const std::vector<uint8_t> is_tail = main_mode != Mode::I32 ? pick_tail(c, ranges[ri]) : std::vector<uint8_t>(ranges[ri].g1 - ranges[ri].g0, 0);
                 size_t t_items = 0, t_cols = 0;
-                uint32_t longest_main = 0;
+                uint32_t longest_main = 0, longest_all = 0;
                 for (uint32_t g = ranges[ri].g0; g < ranges[ri].g1; ++g) {
+                    longest_all = std::max(longest_all, c->groups[g].ncols);
                     if (is_tail[g - ranges[ri].g0]) { t_items += 64; t_cols += (size_t)64 * c->groups[g].ncols; }
                     else longest_main = std::max(longest_main, c->groups[g].ncols);
                 }
@@ -1154,7 +1157,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                     int per_cu = 1;
                     if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, c->batch_now && !rotated[q], &per_cu)) return 1;
                     const uint64_t cols = ranges[ri].cols * (main_mode == Mode::I32 ? 2 : 1);
-                    if (qps[q].resident) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_main * 64);
+                    if (qps[q].resident) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_all * 64);   // (a batch takes every group)
                     else need_bnd = std::max<uint64_t>(need_bnd, std::min<uint64_t>(cols, std::max<uint64_t>(budget, longest_main)) * 64);
                     launch_total += (size_t)qps[q].passes * (size_t)(cols / std::max<uint64_t>(budget, 1) + 2);
                 }
@@ -1181,7 +1184,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 tail_items = std::max<size_t>(tail_items, dp->tail.n);
             }
         HIP_TRY(c->d_bnd.reserve(need_bnd));
-        if (alternate || (c->opt_resident && !streaming)) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
+        if (alternate || c->batch_now) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;

@@ -138,7 +138,7 @@ def sample_check(qa_list, lens, codes_of, sm, threads, gpu_scores_of, budget_s, 
     return ok, stride, len(idx), int(sub_lens.astype(np.int64).sum()), wt, kind
 
 
-def pmc_profile(workload, scale, plan, kernel):
+def pmc_profile(workload, scale, plan, kernel, launches):
     """PMC summary of exactly this configuration + launch plan, if one is committed under profiles/ (rocprofv3 --pmc
     passes, tools/profile_bench.sh + tools/summarize_profile.py); None otherwise -- a number from another
     configuration is not this run's traffic."""
@@ -148,7 +148,8 @@ def pmc_profile(workload, scale, plan, kernel):
             d = json.load(open(fn))
         except Exception:
             continue
-        if d.get("workload_key") == workload and abs(float(d.get("scale", -1)) - scale) < 1e-9 and d.get("plan") == plan and d.get("kernel") == kernel:
+        if (d.get("workload_key") == workload and abs(float(d.get("scale", -1)) - scale) < 1e-9 and d.get("plan") == plan and d.get("kernel") == kernel
+                and d.get("kernel_launches_per_search") == launches):
             d["file"] = os.path.relpath(fn, ROOT)
             best = d
     return best
@@ -408,7 +409,7 @@ def main():
         single_kernel = nq == 1                                    # one query = one kernel instantiation: per-launch figures are meaningful
         achieved = (alg_bytes / pipe_launches) / (per_launch_ms * 1e-3) / 1e9 if single_kernel else alg_bytes / (k_ms_mean * 1e-3) / 1e9
         plan_key = {"rows_per_wave": plans[-1]["rows_per_wave"], "waves": plans[-1]["waves"], "passes": plans[-1]["passes"]}
-        prof = pmc_profile(args.workload, args.scale, plan_key, kernel_name) if (world == 1 and single_kernel) else None
+        prof = pmc_profile(args.workload, args.scale, plan_key, kernel_name, pipe_launches) if (world == 1 and single_kernel) else None
         traffic = prof["hbm_bytes_per_launch"] if prof else None
         cells_real = q_real * float(my_residues)
         kernel_gcups = cells_real / (k_ms_mean * 1e-3) / 1e9

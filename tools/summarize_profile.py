@@ -77,6 +77,7 @@ def main():
         traffic = {
             "workload_key": (cfg.get("workload", "c2").split(":")[0]), "scale": cfg.get("scale", 1.0), "plan": cfg.get("plan"),
             "sq_insts_valu_per_launch": mean("SQ_INSTS_VALU"),
+            "kernel_launches_per_search": (line.get("roofline") or {}).get("kernel_launches_per_search"),
             "kernel_avg_ns": float(rows[0]["AverageNs"]), "kernel_calls": int(rows[0]["Calls"]),
             "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE, separate passes (profiles/{rnd}_{label}_pmc_summary.csv)",
             "kernel": dominant,

@@ -169,3 +169,38 @@ def test_c5_ring_wrap_at_natural_occupancy():
     for k in range(len(w["m"])):
         os_, oi = port.topr(dyn[k, :w["n"]], 20)
         assert np.array_equal(ts[k], os_) and np.array_equal(ti[k], oi), k
+
+
+def test_query_batch_group_resident_launch():
+    """40 queries of 300-1 000 residues against a 170 000-sequence database (c2-shaped, 1.0e8 residues, with its long-sequence
+    tail): by default ONE group-resident launch whose items are (group, query) pairs -- every group through the pipeline kernel,
+    queries of 3 to 8 passes side by side -- against the score matrix of the reference, and against one launch per query and pass."""
+    import bench
+    from swimm_amd import synth
+    shard = bench.build_shard(7, 0.17)
+    rng = np.random.default_rng(11)
+    ms = np.sort(rng.integers(300, 1000, 40)).astype(np.uint16)
+    qa = [host.recode(synth.residues(7, 2000 + k, 0, int(m))) for k, m in enumerate(ms)]
+    a = np.concatenate(qa)
+    disp = np.concatenate([[0], np.cumsum(ms.astype(np.int64))]).astype(np.uint32)
+    w = {"lengths": shard["lengths"], "codes": shard["codes"], "offs": np.concatenate([[0], np.cumsum(shard["lengths"].astype(np.int64))]),
+         "a": a, "m": ms, "disp": disp, "matrix": "blosum62", "residues": shard["residues"], "n": shard["n"],
+         "query_residues": int(ms.astype(np.int64).sum())}
+    sm = matrix("blosum62")
+    with hip_backend.HipSearcher(0) as s:
+        s.set_queries(a, ms, disp, sm, 10, 2)
+        s.add_sequences(shard["lengths"], shard["codes"], 0)
+        stride = (shard["n"] + 127) // 128 * 128
+        got, _ = s.search(stride)
+        st, name = s.last_stats(), s.last_kernel_name(len(ms) - 1)
+        ts, ti, _ = s.search_topr(20, shard["n"])
+        s.set_option("resident", 0)
+        other, _ = s.search(stride)
+        st0 = s.last_stats()
+    assert name.endswith("true, true>(swimm::PipeParams)") and st["launches"] <= 6 < st0["launches"], (name, st, st0)
+    assert np.array_equal(got, other)
+    want, idx = oracle_matrix(w)
+    _check_matrix(got[:, :shard["n"]], want, idx, "query batch")
+    for k in range(len(ms)):
+        os_, oi = port.topr(got[k, :shard["n"]], 20)
+        assert np.array_equal(ts[k], os_) and np.array_equal(ti[k], oi), k

@@ -1061,8 +1061,9 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         // A batch launch is one persistent kernel for the whole batch: lane-systolic tail kernels launched beside it would
         // find no free slot until it ends (measured: c3 -16 %, a 1e8-residue database -25 %).  So a batch takes EVERY group
         // through the pipeline kernel -- which is fine as long as the longest item (longest group x the passes of the
-        // longest query) is small beside a workgroup's share of the batch; otherwise (c3: a 35 000-residue sequence is 2.3
-        // shares) the batch is not formed and the queries run one launch per pass beside their tail kernels.
+        // longest query; the queue hands it out first) is at most half a workgroup's share of the batch; otherwise (c3: a
+        // 35 000-residue sequence is 2.3 shares) the batch is not formed and the queries run one launch per pass beside their
+        // tail kernels.
         double pass_sum = 0;
         uint32_t max_passes = 1;
         for (uint32_t q = 0; q < qn; ++q)
@@ -1073,7 +1074,10 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         int per_cu = 1;
         if (wgs_per_cu(c, main_mode, batch_T, batch_W, true, &per_cu)) return 1;
         const double share = pass_sum * (double)c->total_cols / n_workgroups(c, per_cu);
-        if (c->opt_resident < 0 && (double)longest_cols * max_passes > 0.25 * share) c->batch_now = false;
+        if (dbg)
+            fprintf(stderr, "swimm_hip: batch of %.0f passes, shape %d x %d: longest item %u columns x %u passes, a workgroup's share %.0f column-passes, %zu groups for %d workgroups\n",
+                    pass_sum, batch_W, batch_T, longest_cols, max_passes, share, c->groups.size(), n_workgroups(c, per_cu));
+        if (c->opt_resident < 0 && (double)longest_cols * max_passes > 0.5 * share) c->batch_now = false;
         // ... and it pays on a database that is small for the chip: with few groups per workgroup every per-pass launch fills and
         // drains its pipelines for two or three items and ends unbalanced (1e8 residues: +13-15 %); with dozens of groups per
         // workgroup the per-pass launches with per-query shapes are 2-3 % ahead (c5 at 10 %: 8 470 vs 8 250 GCUPS)

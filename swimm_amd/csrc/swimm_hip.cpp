@@ -370,6 +370,14 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
     return 0;
 }
 
+// upper bound of the profile elements of a query batch (25 codes x rows padded to at most 16 x 36 and to the lane kernel's 512)
+static uint64_t prof_elems_bound(const uint16_t *qm, uint32_t qn)
+{
+    uint64_t n = 0;
+    for (uint32_t q = 0; q < qn; ++q) n += (uint64_t)kCodes * ((uint64_t)qm[q] + 16 * 36 + 64 * kLaneRows);
+    return n;
+}
+
 // One launch shape for a whole batch of queries (group-resident launches take all queries of one shape in one launch): the
 // 4-wave shapes only -- measured (profiles/r02_ab_batch.txt), the group-resident kernel equals the per-pass kernel with 4-wave
 // workgroups and loses 9 % with 8 -- and the rows per wave that waste the fewest padded rows over the batch at that shape's rate.
@@ -1052,6 +1060,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         // per range instead of one per range and pass)
         c->batch_now = c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && (non_rot >= 2 || streaming))) && non_rot > 0;
     }
+    if ((uint64_t)qn * S > 0xFFFFFFFFull || prof_elems_bound(qm, qn) > 0xFFFFFFFFull) c->batch_now = false;   // (a batch addresses score rows and profiles with 32-bit offsets)
     int batch_T = 0, batch_W = 0;
     // (no register room is reserved for the lane-systolic waves here: among the 4-wave shapes only the 8-row one would pass that
     // filter, at 6 000 instead of 8 400 GCUPS; the tail kernels are launched first and get their slots, the batch launch's

@@ -108,12 +108,12 @@ hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, int n_wg, const 
 
 // Re-tile one reference-layout chunk (sequences.c:506-526 byte interleave) into device groups.
 hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t vl_groups, uint32_t vl,
-                         const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled,
+                         const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint32_t max_cols /* longest group */, uint8_t *tiled,
                          uint32_t *seq_len /* [dev_groups*128], zeroed; gets every sequence's true length */, hipStream_t s);
 
 // Tile a slab of sorted sequences (concatenated codes + offsets, as in the .seq file) into device groups directly.
 hipError_t launch_tile_sequences(const uint8_t *codes, const uint32_t *seq_off /* [n_seq + 1] */, uint32_t n_seq, const uint64_t *goff,
-                                 const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled, hipStream_t s);
+                                 const uint32_t *gcols, uint32_t dev_groups, uint32_t max_cols /* longest group */, uint8_t *tiled, hipStream_t s);
 
 // appends the slots whose score is >= thr (tier left its exact range) to list (up to cap) and zeroes them
 hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, int thr, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s);

@@ -1018,10 +1018,14 @@ __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__r
                               const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols,
                               uint8_t *__restrict__ tiled, uint32_t *__restrict__ seq_len)
 {
+    // (a database that streams in is tiled while the pipeline kernel's waves, priority 1-3, fill the chip: at the default
+    // priority 0 these few memory-bound waves would wait for issue slots and hold up the next chunk's copy)
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t g = blockIdx.x;
     const uint32_t nch = gcols[g] / kChunkCols;
     const uint32_t per = kGroupSeqs / vl;            // VL-groups per device group
-    for (uint32_t idx = threadIdx.x; idx < nch * 64; idx += blockDim.x) {
+    // (blockIdx.y: a long group is shared by several blocks -- a chunk of 5 000-residue sequences has fewer groups than the chip has CUs)
+    for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nch * 64; idx += gridDim.y * blockDim.x) {
         const uint32_t c = idx >> 6, l = idx & 63;
         uint32_t w[2];
 #pragma unroll
@@ -1049,12 +1053,19 @@ __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__r
     }
 }
 
+// blocks per group of the two tiling kernels: four (chunk, lane) pairs per thread for the longest group, at most 32
+static unsigned tile_slices(uint32_t max_cols)
+{
+    const uint32_t pairs = max_cols / kChunkCols * 64;
+    return std::max(1u, std::min(32u, (pairs + 1023) / 1024));
+}
+
 hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t vl_groups, uint32_t vl,
-                         const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled, uint32_t *seq_len,
+                         const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint32_t max_cols, uint8_t *tiled, uint32_t *seq_len,
                          hipStream_t s)
 {
     if (dev_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(retile_kernel, dim3(dev_groups), dim3(256), 0, s, b, n, disp, vl_groups, vl, goff, gcols, tiled, seq_len);
+    hipLaunchKernelGGL(retile_kernel, dim3(dev_groups, tile_slices(max_cols)), dim3(256), 0, s, b, n, disp, vl_groups, vl, goff, gcols, tiled, seq_len);
     return hipGetLastError();
 }
 
@@ -1067,9 +1078,10 @@ __global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const u
                                       const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols,
                                       uint8_t *__restrict__ tiled)
 {
+    __builtin_amdgcn_s_setprio(3);                    // (see retile_kernel)
     const uint32_t g = blockIdx.x;
     const uint32_t nch = gcols[g] / kChunkCols;
-    for (uint32_t idx = threadIdx.x; idx < nch * 64; idx += blockDim.x) {
+    for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nch * 64; idx += gridDim.y * blockDim.x) {
         const uint32_t c = idx >> 6, l = idx & 63;
         uint32_t w[2];
 #pragma unroll
@@ -1078,13 +1090,22 @@ __global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const u
             uint32_t word = 0x18181818u;              // four padding codes (24)
             if (s < n_seq) {
                 const uint32_t b0 = seq_off[s], len = seq_off[s + 1] - b0;
-                word = 0;
+                const uint32_t col = c * kChunkCols;
+                if (col + kChunkCols <= len) {
+                    // four residues inside the sequence: one (unaligned) dword, codes above 24 clamped to the padding code
+                    uint32_t x;
+                    __builtin_memcpy(&x, codes + (size_t)b0 + col, 4);
+                    const uint32_t over = ((x & 0x80808080u) | (((x & 0x7f7f7f7fu) + 0x67676767u) & 0x80808080u)) >> 7;   // 1 per byte > 24
+                    const uint32_t m = over * 0xffu;
+                    word = (x & ~m) | (0x18181818u & m);
+                } else {
+                    word = 0;
 #pragma unroll
-                for (int jj = 0; jj < kChunkCols; ++jj) {
-                    const uint32_t col = c * kChunkCols + jj;
-                    uint32_t code = 24;
-                    if (col < len) { code = codes[(size_t)b0 + col]; if (code > 24) code = 24; }
-                    word |= code << (8 * jj);
+                    for (int jj = 0; jj < kChunkCols; ++jj) {
+                        uint32_t code = 24;
+                        if (col + jj < len) { code = codes[(size_t)b0 + col + jj]; if (code > 24) code = 24; }
+                        word |= code << (8 * jj);
+                    }
                 }
             }
             w[hh] = word;
@@ -1094,10 +1115,10 @@ __global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const u
 }
 
 hipError_t launch_tile_sequences(const uint8_t *codes, const uint32_t *seq_off, uint32_t n_seq, const uint64_t *goff,
-                                 const uint32_t *gcols, uint32_t dev_groups, uint8_t *tiled, hipStream_t s)
+                                 const uint32_t *gcols, uint32_t dev_groups, uint32_t max_cols, uint8_t *tiled, hipStream_t s)
 {
     if (dev_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_sequences_kernel, dim3(dev_groups), dim3(256), 0, s, codes, seq_off, n_seq, goff, gcols, tiled);
+    hipLaunchKernelGGL(tile_sequences_kernel, dim3(dev_groups, tile_slices(max_cols)), dim3(256), 0, s, codes, seq_off, n_seq, goff, gcols, tiled);
     return hipGetLastError();
 }
 

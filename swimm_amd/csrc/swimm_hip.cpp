@@ -10,7 +10,9 @@
 #include "sw_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +20,7 @@
 #include <functional>
 #include <cxxabi.h>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <string>
 #include <thread>
@@ -66,6 +69,13 @@ struct DevBuf {   // grow-only device scratch
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// the lengths of a run of bulk groups, longest first, with the makespan factors already worked out for it
+struct BulkCols {
+    std::vector<uint32_t> cols;
+    uint64_t total = 0;
+    std::map<int, double> cache;    // n_wg -> LPT makespan / mean load
+};
+
 struct Plan {      // static partition of a work list over n_wg persistent workgroups
     int n_wg = 0;
     DevBuf<Item> items;          // grouped by workgroup (static partition)
@@ -103,6 +113,8 @@ struct LaneScratch {
     DevBuf<uint32_t> queue, prog;
     void release() { bnd[0].release(); bnd[1].release(); queue.release(); prog.release(); }
 };
+
+struct Uploader;      // the thread that copies a lazily uploaded database (below, with upload_chunk)
 
 struct ChunkRec {
     uint8_t *d_tiled = nullptr;
@@ -156,6 +168,7 @@ struct swimm_hip_ctx {
     int opt_resident = -1;              // group-resident batch launches: -1 = when the batch has two or more queries that are not rotated, 0 never, 1 always
     int opt_lane_room = -1;             // launch shapes must leave a lane-systolic wave its registers: -1 = when the database has a long-sequence tail, 0 never, 1 always
     bool batch_now = false;             // the search in progress runs its non-rotated queries as group-resident batch launches
+    std::vector<uint8_t> stream_tail;   // streaming search: the tail flags of the whole database (pick_tail)
     bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
     DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
     int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
@@ -170,9 +183,7 @@ struct swimm_hip_ctx {
     int opt_lane_acquire = 0;           // 1: chained lane passes take an agent-scope acquire after every progress poll (default: sc1 loads only)
     int opt_wg_limit = 0;               // > 0: at most this many persistent workgroups per pipeline launch (tests: long per-workgroup item sequences on a small database)
     // caches that depend on the resident database / the code objects
-    std::vector<uint32_t> bulk_cols_sorted;  // lengths of the groups the pipeline kernel aligns, longest first (built on demand)
-    uint64_t bulk_cols_total = 0;
-    std::map<int, double> imbalance_cache;   // n_wg -> LPT makespan / mean load of the resident database (bulk groups)
+    BulkCols bulk;                      // the resident database's bulk groups (built on demand) and their makespan factors
     int regs_cache[2][3][40] = {};      // VGPRs of sw_pipe_kernel<T, tier, dynamic, group-resident or not>, looked up once
     DevBuf<uint32_t> d_queue;           // one cursor per pipeline launch of a search
     uint32_t queue_next = 0;
@@ -195,6 +206,10 @@ struct swimm_hip_ctx {
     DevBuf<int32_t> d_scores;
     DevBuf<int16_t> d_prof;
     DevBuf<uint2> d_bnd, d_bnd_b;       // pass-boundary rows; the second one for the queries whose passes run on stream_b
+    DevBuf<uint2> d_bnd_c;              // ... and a third for the group-resident launches of a database that streams in (three ranges in flight)
+    Uploader *up = nullptr;             // the thread that copies a lazily uploaded database (created with the first recorded chunk)
+    void *pin = nullptr;                // pinned arena the work lists travel through (list_copy)
+    size_t pin_cap = 0, pin_used = 0;
     DevBuf<int64_t> d_gbase;
     DevBuf<uint32_t> d_gvalid;
     DevBuf<unsigned long long> d_keys;
@@ -218,8 +233,7 @@ void release_plans(swimm_hip_ctx *c)
 {
     for (auto &kv : c->plans) { kv.second.main.release(); kv.second.tail.release(); }
     c->plans.clear();
-    c->imbalance_cache.clear();
-    c->bulk_cols_sorted.clear();
+    c->bulk.cols.clear(); c->bulk.total = 0; c->bulk.cache.clear();
 }
 
 int regs_to_waves_per_simd(int regs)
@@ -255,6 +269,39 @@ bool resident_for(const swimm_hip_ctx *c, int passes) { (void)passes; return c->
 
 // a run of consecutive device groups that is searched as one unit: the whole resident database (work lists cached),
 // or one chunk of a database that is still streaming in
+// Work lists travel on the upload stream -- except while a search streams its database in: the upload stream then
+// belongs to the uploader thread's chunk copies (0.1 GB each), and the lists take the promotion stream, idle until
+// the ladder at the end of the search.
+hipStream_t list_stream(const swimm_hip_ctx *c) { return c->streaming_now ? c->stream3 : c->stream_up; }
+
+// ... and through a pinned arena: a copy from pageable memory would queue for the runtime's staging buffers behind
+// the uploader's chunk copies (measured: 1.2 ms per range's lists instead of 0.3).  list_sync() ends a batch of copies.
+int list_copy(swimm_hip_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    if (c->pin_used + bytes > c->pin_cap) {
+        HIP_TRY(hipStreamSynchronize(list_stream(c)));        // copies in flight still read the arena
+        c->pin_used = 0;
+        if (bytes > c->pin_cap) {
+            if (c->pin) { HIP_TRY(hipHostFree(c->pin)); c->pin = nullptr; c->pin_cap = 0; }
+            const size_t cap = std::max<size_t>(2 * bytes, (size_t)4 << 20);
+            HIP_TRY(hipHostMalloc(&c->pin, cap, hipHostMallocDefault));
+            c->pin_cap = cap;
+        }
+    }
+    char *at = (char *)c->pin + c->pin_used;
+    memcpy(at, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, list_stream(c)));
+    c->pin_used += (bytes + 255) & ~(size_t)255;
+    return 0;
+}
+int list_sync(swimm_hip_ctx *c)
+{
+    HIP_TRY(hipStreamSynchronize(list_stream(c)));
+    c->pin_used = 0;
+    return 0;
+}
+
 struct Range { uint32_t g0 = 0, g1 = 0; uint64_t cols = 0; };
 Range whole_range(const swimm_hip_ctx *c) { Range r; r.g0 = 0; r.g1 = (uint32_t)c->groups.size(); r.cols = c->total_cols; return r; }
 
@@ -271,19 +318,12 @@ int n_workgroups(const swimm_hip_ctx *c, int per_cu)
 // greedy schedule (what the dynamic queue, and the static partition, produce) over the mean load.  1.00x for a
 // large database; a small one whose longest group is a sizeable part of a workgroup's share reaches 1.4 - 1.9
 // with 3 - 4 workgroups per CU, and then fewer, larger workgroups are the better launch shape.
-double plan_imbalance(swimm_hip_ctx *c, int n_wg)
+static double lpt_imbalance(BulkCols &b, int n_wg)
 {
-    auto it = c->imbalance_cache.find(n_wg);
-    if (it != c->imbalance_cache.end()) return it->second;
-    if (c->bulk_cols_sorted.empty() && !c->groups.empty()) {     // once per database: the bulk groups' lengths, longest first
-        const std::vector<uint8_t> is_tail = pick_tail(c, whole_range(c));
-        c->bulk_cols_total = 0;
-        for (uint32_t g = 0; g < c->groups.size(); ++g)
-            if (!is_tail[g]) { c->bulk_cols_sorted.push_back(c->groups[g].ncols); c->bulk_cols_total += c->groups[g].ncols; }
-        std::sort(c->bulk_cols_sorted.begin(), c->bulk_cols_sorted.end(), std::greater<uint32_t>());
-    }
-    const std::vector<uint32_t> &cols = c->bulk_cols_sorted;
-    const uint64_t total = c->bulk_cols_total;
+    auto it = b.cache.find(n_wg);
+    if (it != b.cache.end()) return it->second;
+    const std::vector<uint32_t> &cols = b.cols;
+    const uint64_t total = b.total;
     double r = 1.0;
     if (!cols.empty() && total > 0) {
         const int n = std::max(1, std::min<int>(n_wg, (int)cols.size()));
@@ -300,8 +340,24 @@ double plan_imbalance(swimm_hip_ctx *c, int n_wg)
             r = (double)mx / ((double)total / n_wg);   // fewer groups than workgroups: the idle ones count
         }
     }
-    c->imbalance_cache[n_wg] = r;
+    b.cache[n_wg] = r;
     return r;
+}
+
+// the bulk groups of a range (those the tail picker leaves to the pipeline kernel), longest first
+static void bulk_cols_of(const swimm_hip_ctx *c, const Range &rg, BulkCols &b)
+{
+    const std::vector<uint8_t> is_tail = pick_tail(c, rg);
+    b.cols.clear(); b.total = 0; b.cache.clear();
+    for (uint32_t g = rg.g0; g < rg.g1; ++g)
+        if (!is_tail[g - rg.g0]) { b.cols.push_back(c->groups[g].ncols); b.total += c->groups[g].ncols; }
+    std::sort(b.cols.begin(), b.cols.end(), std::greater<uint32_t>());
+}
+
+double plan_imbalance(swimm_hip_ctx *c, int n_wg)
+{
+    if (c->bulk.cols.empty() && !c->groups.empty()) bulk_cols_of(c, whole_range(c), c->bulk);     // once per database
+    return lpt_imbalance(c->bulk, n_wg);
 }
 
 // Measured throughput (GCUPS of padded cells) of every launch shape of the f16-tier pipeline kernel: rows per wave
@@ -329,9 +385,14 @@ static const float kShapeGcups[8][16] = {
 // admitted (e.g. 3 waves x 144, 4 x 104).
 // `overlapped`: the query runs beside two others (one-pass queries in rotation, see search_device), which cover the
 // workgroups that finish early: the makespan term is dropped.
-int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bool overlapped, QueryPlan *out)
+// `rg` / `rb`: plan for one range of a database that is streaming in (its columns, its own makespan factors) instead
+// of the whole resident database.
+int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bool overlapped, QueryPlan *out,
+                const Range *rg = nullptr, BulkCols *rb = nullptr)
 {
-    double best_cost = -1;
+    struct Cand { double base; double pass_base; int T, W, passes, n_wg; };
+    std::vector<Cand> cands;
+    const double cols = rg ? (double)rg->cols : (double)c->total_cols;
     for (int ti = 7; ti >= 0; --ti) {
         const int T = 8 + 4 * ti;
         if (c->opt_T && T != c->opt_T) continue;
@@ -355,17 +416,26 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
             // seconds: every pass aligns T x W rows against the whole resident database at the shape's rate, and costs
             // a launch (pipeline fill and drain, staging, the last workgroups running alone: ~0.15 ms, which is what
             // makes fewer, taller passes the better plan on a database of 1e8 residues)
-            const double pass_s = (double)c->total_cols * kGroupSeqs * T * W / ((double)kShapeGcups[ti][W - 1] * 1e9)
-                                  * (overlapped ? 1.0 : plan_imbalance(c, n_workgroups(c, per_cu)));
-            const double cost = passes * (pass_s + 150e-6);
-            if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
-                best_cost = cost;
-                out->T = T; out->W = W; out->passes = passes; out->mpad = (uint32_t)(passes * W * T);
-            }
+            const double pass_base = cols * kGroupSeqs * T * W / ((double)kShapeGcups[ti][W - 1] * 1e9);
+            cands.push_back(Cand{passes * (pass_base + 150e-6), pass_base, T, W, passes, n_workgroups(c, per_cu)});
+        }
+    }
+    // The makespan factor (>= 1) of a shape costs a simulated schedule per distinct workgroup count: cheapest shapes
+    // first, and stop at the first one that cannot win even with a perfectly even schedule.  (The order of equal
+    // costs is the order of the loops above: taller strips first.)
+    std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.base < b.base; });
+    double best_cost = -1;
+    for (const Cand &k : cands) {
+        if (best_cost >= 0 && k.base >= best_cost * (1.0 - 1e-9)) break;
+        const double imb = overlapped ? 1.0 : (rb ? lpt_imbalance(*rb, k.n_wg) : plan_imbalance(c, k.n_wg));
+        const double cost = k.passes * (k.pass_base * imb + 150e-6);
+        if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
+            best_cost = cost;
+            out->T = k.T; out->W = k.W; out->passes = k.passes; out->mpad = (uint32_t)(k.passes * k.W * k.T);
         }
     }
     // (no admissible shape leaves a lane-systolic wave its registers, e.g. under a max_waves cap: the tail then shares)
-    if (best_cost < 0 && room_for_lane_waves) return choose_plan(c, mode, m, false, overlapped, out);
+    if (best_cost < 0 && room_for_lane_waves) return choose_plan(c, mode, m, false, overlapped, out, rg, rb);
     if (best_cost < 0) { fail("no kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W); return 1; }
     return 0;
 }
@@ -470,18 +540,16 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
             }
         }
         HIP_TRY(pl.split_items.reserve(split.size()));
-        HIP_TRY(hipMemcpyAsync(pl.split_items.p, split.data(), split.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream_up));
-        HIP_TRY(hipStreamSynchronize(c->stream_up));   // `split` dies here
+        if (list_copy(c, pl.split_items.p, split.data(), split.size() * sizeof(Item))) return 1;
     }
     HIP_TRY(pl.queue_items.reserve(sorted.size()));
-    HIP_TRY(hipMemcpyAsync(pl.queue_items.p, sorted.data(), sorted.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream_up));
+    if (list_copy(c, pl.queue_items.p, sorted.data(), sorted.size() * sizeof(Item))) return 1;
     HIP_TRY(pl.items.reserve(items.size()));
     HIP_TRY(pl.wg_first.reserve(first.size()));
     HIP_TRY(pl.wg_chunks.reserve(chunks.size()));
-    HIP_TRY(hipMemcpyAsync(pl.items.p, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream_up));
-    HIP_TRY(hipMemcpyAsync(pl.wg_first.p, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream_up));
-    HIP_TRY(hipMemcpyAsync(pl.wg_chunks.p, chunks.data(), chunks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream_up));
-    HIP_TRY(hipStreamSynchronize(c->stream_up));   // the host vectors die here
+    if (list_copy(c, pl.items.p, items.data(), items.size() * sizeof(Item)) ||
+        list_copy(c, pl.wg_first.p, first.data(), first.size() * sizeof(uint32_t)) ||
+        list_copy(c, pl.wg_chunks.p, chunks.data(), chunks.size() * sizeof(uint32_t)) || list_sync(c)) return 1;
     return 0;
 }
 
@@ -498,8 +566,7 @@ int upload_lane_items(swimm_hip_ctx *c, std::vector<LaneItem> &v, LaneList &ll)
     ll.cols = cols;
     ll.cell_cols = cols;
     HIP_TRY(ll.items.reserve(v.size()));
-    HIP_TRY(hipMemcpyAsync(ll.items.p, v.data(), v.size() * sizeof(LaneItem), hipMemcpyHostToDevice, c->stream_up));
-    HIP_TRY(hipStreamSynchronize(c->stream_up));
+    if (list_copy(c, ll.items.p, v.data(), v.size() * sizeof(LaneItem)) || list_sync(c)) return 1;
     return 0;
 }
 
@@ -510,6 +577,10 @@ int upload_lane_items(swimm_hip_ctx *c, std::vector<LaneItem> &v, LaneList &ll)
 std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> flag per group of the range
 {
     const uint32_t n = rg.g1 - rg.g0;
+    // (a database that is streaming in: "long" is judged against the whole database, not against the range that
+    // happens to hold the group -- a range of nothing but the longest sequences is bulk work like any other)
+    if (c->streaming_now && c->stream_tail.size() == c->groups.size() && n != c->groups.size())
+        return std::vector<uint8_t>(c->stream_tail.begin() + rg.g0, c->stream_tail.begin() + rg.g1);
     std::vector<uint8_t> is_tail(n, 0);
     if (c->opt_tail_mode == 2) return is_tail;                        // never
     if (c->opt_tail_mode == 1) { std::fill(is_tail.begin(), is_tail.end(), 1); return is_tail; }   // always
@@ -630,9 +701,14 @@ static int timed_launch(swimm_hip_ctx *c, Mode mode, int T, int W, int n_wg, con
         HIP_TRY(hipEventCreate(&e));
         c->launch_ev.push_back(e);
     }
+    const bool dbg = getenv("SWIMM_HIP_DEBUG") != nullptr;
+    const double t0 = dbg ? now_s() : 0;
     HIP_TRY(hipEventRecord(c->launch_ev[c->launch_ev_used], st));
+    const double t1 = dbg ? now_s() : 0;
     HIP_TRY(launch_pipe(mode, T, W, n_wg, p, st));
+    const double t2 = dbg ? now_s() : 0;
     HIP_TRY(hipEventRecord(c->launch_ev[c->launch_ev_used + 1], st));
+    if (dbg) fprintf(stderr, "swimm_hip: host time of a timed launch: event %.3f ms, launch %.3f ms, event %.3f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
     c->launch_ev_used += 2;
     return 0;
 }
@@ -901,6 +977,8 @@ int upload_chunk(swimm_hip_ctx *c, ChunkRec &r)
     if (r.uploaded) return 0;
     hipStream_t s = c->stream_up;
     const uint32_t dev_groups = r.n_groups;
+    uint32_t max_cols = 0;
+    for (uint32_t x : r.gcols) max_cols = std::max(max_cols, x);
     const double t_up0 = now_s();
     HIP_TRY(c->up_gcols.reserve(dev_groups));
     HIP_TRY(c->up_goff.reserve(dev_groups));
@@ -915,14 +993,14 @@ int upload_chunk(swimm_hip_ctx *c, ChunkRec &r)
         HIP_TRY(hipMemcpyAsync(c->up_disp.p, r.h_disp, r.group_count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_b, r.vD, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(c->ev_copied, s));
-        HIP_TRY(launch_retile(c->up_b.p, c->up_n.p, c->up_disp.p, r.group_count, r.vl, c->up_goff.p, c->up_gcols.p, dev_groups, r.d_tiled, r.d_len, s));
+        HIP_TRY(launch_retile(c->up_b.p, c->up_n.p, c->up_disp.p, r.group_count, r.vl, c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled, r.d_len, s));
     } else {
         HIP_TRY(c->up_b.reserve(std::max<uint64_t>(r.code_bytes, 16)));
         HIP_TRY(c->up_off.reserve(r.off.size()));
         HIP_TRY(hipMemcpyAsync(c->up_off.p, r.off.data(), r.off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_codes, r.code_bytes, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(c->ev_copied, s));
-        HIP_TRY(launch_tile_sequences(c->up_b.p, c->up_off.p, (uint32_t)r.n_seq, c->up_goff.p, c->up_gcols.p, dev_groups, r.d_tiled, s));
+        HIP_TRY(launch_tile_sequences(c->up_b.p, c->up_off.p, (uint32_t)r.n_seq, c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled, s));
     }
     HIP_TRY(hipEventRecord(r.ready, s));
     HIP_TRY(hipEventSynchronize(c->ev_copied));      // the caller's buffers have been read
@@ -933,6 +1011,81 @@ int upload_chunk(swimm_hip_ctx *c, ChunkRec &r)
     r.uploaded = true;
     r.h_b = nullptr; r.h_n = nullptr; r.h_disp = nullptr; r.h_codes = nullptr;
     std::vector<uint32_t>().swap(r.off);
+    return 0;
+}
+
+// The uploader of a database that streams in (option "lazy_upload"): a thread of its own, one per context, started when
+// the first chunk is recorded and parked between searches.  The copies come from pageable memory, so each one blocks its
+// caller for the length of the transfer: on this thread the link is busy back to back (0.6 GB in 13-15 ms) while the
+// searching thread plans, builds work lists and launches, and since the link delivers 1.8x faster than the kernels
+// consume, the GPU waits for the first range only.  (A thread per search would do, but its first HIP call costs
+// up to 5 ms on some runs.)
+struct Uploader {
+    swimm_hip_ctx *c;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<size_t> order;      // the job: chunk indices in the order they travel
+    bool have_job = false, busy = false, quit = false, stop = false;
+    size_t issued = 0;              // the first `issued` chunks of `order` have their `ready` event recorded
+    bool failed = false;
+    std::string err;
+
+    explicit Uploader(swimm_hip_ctx *ctx) : c(ctx) { th = std::thread([this]() { run(); }); }
+    ~Uploader()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    void run()
+    {
+        bool dev_ok = hipSetDevice(c->device) == hipSuccess;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&]() { return have_job || quit; });
+            if (quit) return;
+            have_job = false;
+            const std::vector<size_t> job = order;
+            lk.unlock();
+            bool ok = dev_ok;
+            std::string e = ok ? "" : "uploader: hipSetDevice failed";
+            for (size_t i = 0; i < job.size(); ++i) {
+                bool skip;
+                { std::lock_guard<std::mutex> g(mu); skip = stop; }
+                if (ok && !skip && upload_chunk(c, c->chunks[job[i]])) { ok = false; e = g_err; }
+                std::lock_guard<std::mutex> g(mu);
+                issued = i + 1; failed = !ok; err = e;
+                cv.notify_all();
+            }
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void post(const std::vector<size_t> &job)
+    {
+        { std::lock_guard<std::mutex> lk(mu); order = job; issued = 0; failed = false; err.clear(); stop = false; have_job = true; busy = true; }
+        cv.notify_all();
+    }
+    int wait_issued(size_t n, std::string *e)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return issued >= n || failed || !busy; });
+        if (failed) { *e = err; return 1; }
+        return issued >= n ? 0 : 1;
+    }
+    void finish(bool abandon)       // the job has been walked to its end (abandon: without copying what is left)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (abandon) stop = true;
+        cv.wait(lk, [&]() { return !busy; });
+    }
+};
+
+int ensure_uploader(swimm_hip_ctx *c)
+{
+    if (!c->up) c->up = new Uploader(c);
     return 0;
 }
 
@@ -977,7 +1130,8 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     for (const ChunkRec &r : c->chunks) streaming = streaming || !r.uploaded;
     c->streaming_now = streaming;
     std::vector<Range> ranges;
-    std::vector<std::pair<size_t, size_t>> range_chunks;     // streaming: chunks [first, last) of every range
+    std::vector<std::pair<size_t, size_t>> range_chunks;     // streaming: positions [first, last) in `up_order` of every range's chunks
+    std::vector<size_t> up_order;                            // streaming: the chunks in the order they travel
     if (streaming) {
         uint64_t mb = 16, mn = 1, mg = 1, mo = 1;
         for (const ChunkRec &r : c->chunks) {
@@ -985,18 +1139,36 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             mb = std::max<uint64_t>(mb, r.kind == 0 ? r.vD : r.code_bytes); mn = std::max<uint64_t>(mn, r.group_count);
             mg = std::max<uint64_t>(mg, r.n_groups); mo = std::max<uint64_t>(mo, r.off.size());
         }
-        // Consecutive chunks form a range; every range is about twice the one before it (the first is one chunk): the
-        // link copies faster than the kernels consume, so while range k is aligned range k+1 arrives in full, the first
-        // kernel starts after one chunk's copy, and most of the database is still aligned by a few large launches.
-        uint64_t prev = 0;
-        for (size_t i = 0; i < c->chunks.size();) {
-            Range rg; rg.g0 = c->chunks[i].group0; rg.g1 = rg.g0; rg.cols = 0;
+        // Consecutive chunks form a range, and every range is as large as it can be without the GPU running dry before
+        // it has arrived: the link delivers a chunk in bytes / 40 GB/s, the kernels consume it in (rows of all queries) x
+        // residues / 8 000 GCUPS -- 1.9x longer for one 375-row query, so the first range is one chunk, the second one or
+        // two, and the rest of the database follows in two or three large launches; a batch of long queries is
+        // compute-bound from the first chunk on and runs as two ranges.
+        // The end of the database with the LONGER sequences travels first: consecutive ranges run on alternating
+        // streams, so the few long chains a range ends with are covered by the next range's workgroups -- and the last
+        // range, which nothing covers, is then the one with the short sequences, whose launches end evenly.
+        c->stream_tail.clear();
+        c->stream_tail = pick_tail(c, whole_range(c));
+        const size_t nc = c->chunks.size();
+        const bool descending = nc > 1 && (double)c->chunks[nc - 1].cols / std::max<uint32_t>(1, c->chunks[nc - 1].n_groups) >
+                                              (double)c->chunks[0].cols / std::max<uint32_t>(1, c->chunks[0].n_groups);
+        for (size_t i = 0; i < nc; ++i) up_order.push_back(descending ? nc - 1 - i : i);
+        double rows = 0;
+        for (uint32_t q = 0; q < qn; ++q) rows += qm[q];
+        auto up_s = [&](const ChunkRec &r) { return (double)(r.kind == 0 ? r.vD : r.code_bytes) / 40e9; };
+        auto dp_s = [&](const ChunkRec &r) { return 0.85 * rows * (double)r.cols * kGroupSeqs / 8000e9; };   // (rather too short: the GPU must not wait)
+        double t_up = 0, t_gpu = 0;
+        for (size_t i = 0; i < nc;) {
+            Range rg; rg.g0 = c->chunks[up_order[i]].group0; rg.g1 = rg.g0 + c->chunks[up_order[i]].n_groups; rg.cols = 0;
             const size_t first = i;
+            double work = 0;
             do {
-                rg.g1 += c->chunks[i].n_groups; rg.cols += c->chunks[i].cols;
+                const ChunkRec &r = c->chunks[up_order[i]];
+                rg.g0 = std::min(rg.g0, r.group0); rg.g1 = std::max(rg.g1, r.group0 + r.n_groups); rg.cols += r.cols;
+                t_up += up_s(r); work += dp_s(r);
                 ++i;
-            } while (i < c->chunks.size() && rg.cols < 2 * prev);
-            prev = rg.cols;
+            } while (i < nc && t_up + up_s(c->chunks[up_order[i]]) <= t_gpu);
+            t_gpu = std::max(t_gpu, t_up) + work;
             ranges.push_back(rg);
             range_chunks.push_back({first, i});
         }
@@ -1007,12 +1179,28 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         if (sync_lengths(c)) return 1;
         ranges.push_back(whole_range(c));
     }
+    // The uploader (Uploader, above) walks the chunk list from the first moment of the search while this thread plans,
+    // builds work lists and launches.
+    if (streaming) {
+        if (ensure_uploader(c)) return 1;
+        c->up->post(up_order);
+    }
+    auto wait_uploaded = [&](size_t n) -> int {     // until the first n chunks of `up_order` are on their way
+        std::string err;
+        if (c->up->wait_issued(n, &err)) return fail("%s", err.empty() ? "upload failed" : err.c_str());
+        return 0;
+    };
     std::vector<std::map<int, DbPlan>> stream_plans(streaming ? ranges.size() : 0);   // released when the search has drained
     auto release_stream_plans = [&]() {
         for (auto &m : stream_plans) for (auto &kv : m) { kv.second.main.release(); kv.second.tail.release(); }
         stream_plans.clear();
     };
-    struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{[&]() { if (streaming) { (void)hipDeviceSynchronize(); release_stream_plans(); } }};
+    struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{[&]() {
+        if (!streaming) return;
+        if (c->up) c->up->finish(true);          // (an early return: the chunks not yet copied stay where they are)
+        (void)hipDeviceSynchronize();
+        release_stream_plans();
+    }};
 
     // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
@@ -1025,6 +1213,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     if (c->opt_tail_mode != 2 && main_mode != Mode::I32)
         lane_room = c->opt_tail_mode == 1 || (double)longest_cols > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
     if (c->opt_lane_room >= 0) lane_room = c->opt_lane_room != 0 && main_mode != Mode::I32;
+    if (dbg) fprintf(stderr, "swimm_hip: ranges laid out, uploader started %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     std::vector<QueryPlan> qps(qn);
     std::vector<uint8_t> rotated(qn, 0);
     uint32_t n_short = 0;
@@ -1065,7 +1254,9 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     // (no register room is reserved for the lane-systolic waves here: among the 4-wave shapes only the 8-row one would pass that
     // filter, at 6 000 instead of 8 400 GCUPS; the tail kernels are launched first and get their slots, the batch launch's
     // workgroups that do not fit beside them start when they are done)
+    if (dbg) fprintf(stderr, "swimm_hip: rotation decided %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     if (c->batch_now && choose_batch_shape(c, main_mode, qm, rotated, qn, false, &batch_T, &batch_W)) return 1;
+    if (dbg) fprintf(stderr, "swimm_hip: batch shape chosen %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     if (c->batch_now) {
         // A batch launch is one persistent kernel for the whole batch: lane-systolic tail kernels launched beside it would
         // find no free slot until it ends (measured: c3 -16 %, a 1e8-residue database -25 %).  So a batch takes EVERY group
@@ -1086,11 +1277,22 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         if (dbg)
             fprintf(stderr, "swimm_hip: batch of %.0f passes, shape %d x %d: longest item %u columns x %u passes, a workgroup's share %.0f column-passes, %zu groups for %d workgroups\n",
                     pass_sum, batch_W, batch_T, longest_cols, max_passes, share, c->groups.size(), n_workgroups(c, per_cu));
-        if (c->opt_resident < 0 && (double)longest_cols * max_passes > 0.5 * share) c->batch_now = false;
+        // (a database that streams in as several ranges: consecutive ranges overlap on two streams, the long items travel
+        // and start first, and the last range is the one with the short sequences -- the longest item may take 0.9 of
+        // the whole search before it sticks out at the end)
+        const bool ranges_overlap = streaming && ranges.size() > 1;
+        if (c->opt_resident < 0 && (double)longest_cols * max_passes > (ranges_overlap ? 0.9 : 0.5) * share) c->batch_now = false;
         // ... and it pays on a database that is small for the chip: with few groups per workgroup every per-pass launch fills and
         // drains its pipelines for two or three items and ends unbalanced (1e8 residues: +13-15 %); with dozens of groups per
         // workgroup the per-pass launches with per-query shapes are 2-3 % ahead (c5 at 10 %: 8 470 vs 8 250 GCUPS)
         if (c->opt_resident < 0 && !streaming && c->groups.size() >= (size_t)16 * n_workgroups(c, per_cu)) c->batch_now = false;
+    }
+    std::vector<std::vector<QueryPlan>> rqps;       // streaming, per-pass launches: a launch shape per (range, query)
+    std::vector<BulkCols> rbulk;
+    if (streaming && !c->batch_now && ranges.size() > 1) {
+        rqps.assign(ranges.size(), std::vector<QueryPlan>(qn));
+        rbulk.resize(ranges.size());
+        for (size_t ri = 0; ri < ranges.size(); ++ri) bulk_cols_of(c, ranges[ri], rbulk[ri]);
     }
     for (uint32_t q = 0; q < qn; ++q) {
         if (!rotated[q] && c->batch_now) {
@@ -1100,6 +1302,15 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         } else if (!rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;
         if (dbg)
             fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
+        // A database that is streaming in, per-pass launches: every range gets the launch shape that suits ITS groups -- the
+        // range with the longest sequences is small beside the chip (a few long chains over hundreds of workgroups), and
+        // fewer, taller workgroups finish it sooner than the shape that is best for the database as a whole.
+        if (!rqps.empty())
+            for (size_t ri = 0; ri < ranges.size(); ++ri) {
+                if (choose_plan(c, main_mode, qm[q], lane_room, false, &rqps[ri][q], &ranges[ri], &rbulk[ri])) return 1;
+                qps[q].mpad = std::max(qps[q].mpad, rqps[ri][q].mpad);
+                if (dbg) fprintf(stderr, "swimm_hip:   range %zu: T=%d W=%d passes=%d\n", ri, rqps[ri][q].T, rqps[ri][q].W, rqps[ri][q].passes);
+            }
         const uint32_t lane_rows = (uint32_t)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
         qps[q].mpad = std::max(qps[q].mpad, lane_rows);
         qps[q].prof_off = prof_elems;
@@ -1121,6 +1332,13 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     }
     c->last_plans.resize(c->qm.size());
     for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = c->batch_now && !rotated[q]; c->last_plans[qb + q] = qps[q]; }
+    for (auto &rv : rqps)
+        for (uint32_t q = 0; q < qn; ++q) {
+            rv[q].mpad = qps[q].mpad; rv[q].prof_off = qps[q].prof_off;      // one profile per query, padded for the tallest plan
+            rv[q].mode = main_mode; rv[q].dynamic = qps[q].dynamic; rv[q].resident = false;
+        }
+    auto qp_of = [&](size_t ri, uint32_t q) -> const QueryPlan & { return rqps.empty() ? qps[q] : rqps[ri][q]; };
+    if (dbg) fprintf(stderr, "swimm_hip: launch shapes chosen and profiles built %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
@@ -1129,14 +1347,14 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     // the work lists of a (range, launch shape): cached for the resident database, temporary for a streaming chunk
     auto plan_of = [&](size_t ri, uint32_t q, DbPlan **out) -> int {
         int per_cu = 1;
-        if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, c->batch_now && !rotated[q], &per_cu)) return 1;
+        if (wgs_per_cu(c, main_mode, qp_of(ri, q).T, qp_of(ri, q).W, c->batch_now && !rotated[q], &per_cu)) return 1;
         const int n_wg = n_workgroups(c, per_cu);
         if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0 || qps[q].resident, out);
         auto it = stream_plans[ri].find(n_wg);
         if (it == stream_plans[ri].end()) {
             DbPlan &dp = stream_plans[ri][n_wg];
             bool exact = true;
-            for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[ci].lens_known;
+            for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[up_order[ci]].lens_known;
             if (make_db_plan(c, main_mode, n_wg, qps[q].resident, ranges[ri], exact, dp)) return 1;
             *out = &dp;
         } else {
@@ -1145,6 +1363,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         return 0;
     };
 
+    if (dbg) fprintf(stderr, "swimm_hip: profile copy and score reset issued %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     // buffers that later launches grow are sized up front: a reallocation in the middle of the
     // multi-stream phase would free memory a kernel in flight still uses
     {
@@ -1168,13 +1387,14 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 tail_items = std::max(tail_items, t_items);
                 tail_cols = std::max(tail_cols, t_cols);
                 for (uint32_t q = 0; q < qn; ++q) {
-                    if (qps[q].passes <= 1) { launch_total += 2; continue; }
+                    const QueryPlan &qp = qp_of(ri, q);
+                    if (qp.passes <= 1) { launch_total += 2; continue; }
                     int per_cu = 1;
-                    if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, c->batch_now && !rotated[q], &per_cu)) return 1;
+                    if (wgs_per_cu(c, main_mode, qp.T, qp.W, c->batch_now && !rotated[q], &per_cu)) return 1;
                     const uint64_t cols = ranges[ri].cols * (main_mode == Mode::I32 ? 2 : 1);
                     if (qps[q].resident) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_all * 64);   // (a batch takes every group)
                     else need_bnd = std::max<uint64_t>(need_bnd, std::min<uint64_t>(cols, std::max<uint64_t>(budget, longest_main)) * 64);
-                    launch_total += (size_t)qps[q].passes * (size_t)(cols / std::max<uint64_t>(budget, 1) + 2);
+                    launch_total += (size_t)qp.passes * (size_t)(cols / std::max<uint64_t>(budget, 1) + 2);
                 }
             }
         } else
@@ -1198,8 +1418,10 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 tail_cols = std::max<size_t>(tail_cols, dp->tail.cols);
                 tail_items = std::max<size_t>(tail_items, dp->tail.n);
             }
+        if (dbg) fprintf(stderr, "swimm_hip: buffer sizes known %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
         HIP_TRY(c->d_bnd.reserve(need_bnd));
-        if (alternate || c->batch_now) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
+        if (alternate || c->batch_now || streaming) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
+        if (c->batch_now && streaming) HIP_TRY(c->d_bnd_c.reserve(need_bnd));
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
@@ -1224,12 +1446,33 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         c->ev_query.push_back(e);
     }
     std::map<std::pair<int, int>, std::vector<uint32_t>> batches;     // launch shape (T, W) -> queries whose bulk part runs group-resident
+    // the query table of the group-resident launches: per launch shape, the queries in ascending length (the kernel takes
+    // index nq - 1, the longest, first); the same for every range, so it travels once
+    std::map<std::pair<int, int>, size_t> qdesc_off;
+    if (c->batch_now) {
+        std::map<std::pair<int, int>, std::vector<uint32_t>> by_shape;
+        for (uint32_t q = 0; q < qn; ++q)
+            if (qps[q].resident) by_shape[std::make_pair(qps[q].T, qps[q].W)].push_back(q);
+        std::vector<QDesc> qd_host;
+        for (auto &kv : by_shape) {
+            qdesc_off[kv.first] = qd_host.size();
+            for (uint32_t q : kv.second) {
+                if ((uint64_t)q * S > 0xFFFFFFFFull || qps[q].prof_off > 0xFFFFFFFFull) return fail("group-resident batch: score rows beyond 2^32 elements (lower score_mib)");
+                qd_host.push_back(QDesc{(uint32_t)qps[q].prof_off, qps[q].mpad, (uint32_t)qps[q].passes, (uint32_t)((uint64_t)q * S)});
+            }
+        }
+        HIP_TRY(c->d_qdesc.reserve(qd_host.size()));
+        if (list_copy(c, c->d_qdesc.p, qd_host.data(), qd_host.size() * sizeof(QDesc)) || list_sync(c)) return 1;
+    }
+    if (streaming)          // the first range's work lists need its geometry only: ready before its bytes are
+        for (uint32_t q = 0; q < qn; ++q) { DbPlan *dp = nullptr; if (plan_of(0, q, &dp)) return 1; }
     for (size_t ri = 0; ri < ranges.size(); ++ri) {
         if (streaming) {
-            for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci)
-                if (upload_chunk(c, c->chunks[ci])) return 1;   // returns when the host bytes are consumed; the tile kernel is still running
-            ChunkRec &last = c->chunks[range_chunks[ri].second - 1];   // the upload stream is in order: its last chunk's event covers the range
+            if (wait_uploaded(range_chunks[ri].second)) return 1;
+            ChunkRec &last = c->chunks[up_order[range_chunks[ri].second - 1]];   // the upload stream is in order: its last chunk's event covers the range
+            if (dbg) fprintf(stderr, "swimm_hip: range %zu (%llu columns): host copies done %.3f ms after the call began\n", ri, (unsigned long long)ranges[ri].cols, (now_s() - t_begin) * 1e3);
             HIP_TRY(hipStreamWaitEvent(c->stream, last.ready, 0));
+            HIP_TRY(hipStreamWaitEvent(c->stream_b, last.ready, 0));
             HIP_TRY(hipStreamWaitEvent(c->stream2, last.ready, 0));
         }
         // Longest query first: its promotion re-runs (a handful of long serial chains on stream 3) then overlap
@@ -1265,6 +1508,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             }
             DevBuf<uint2> *bnd = &c->d_bnd;
             if (alternate && qps[q].passes > 1 && !rotated[q] && !qps[q].resident && (multi_seen++ & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
+            if (streaming && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
             if (!qps[q].resident && run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
             if (qps[q].resident) {      // every group goes into the group-resident launch of its shape, below
                 if (dp->have_main) batches[std::make_pair(qps[q].T, qps[q].W)].push_back(q);
@@ -1272,7 +1516,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
                 continue;
             }
-            if (dp->have_main && run_passes(c, main_mode, qps[q], dp->main, row, bulk_stream, !streaming && !alternate, *bnd)) return 1;
+            if (dp->have_main && run_passes(c, main_mode, qp_of(ri, q), dp->main, row, bulk_stream, !streaming && !alternate, *bnd)) return 1;
             if (ri + 1 == ranges.size()) {
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
@@ -1283,20 +1527,10 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         // drain once per batch, and no pass waits for the slowest workgroup of the one before it.  Shapes alternate
         // between the two bulk streams.
         if (!batches.empty()) {
-            std::vector<QDesc> qd_host;
-            for (auto &kv : batches) {
-                std::sort(kv.second.begin(), kv.second.end());          // ascending length: the kernel takes index nq - 1 (the longest) first
-                for (uint32_t q : kv.second) {
-                    if ((uint64_t)q * S > 0xFFFFFFFFull || qps[q].prof_off > 0xFFFFFFFFull) return fail("group-resident batch: score rows beyond 2^32 elements (lower score_mib)");
-                    qd_host.push_back(QDesc{(uint32_t)qps[q].prof_off, qps[q].mpad, (uint32_t)qps[q].passes, (uint32_t)((uint64_t)q * S)});
-                }
-            }
-            HIP_TRY(c->d_qdesc.reserve(qd_host.size()));
-            HIP_TRY(hipMemcpyAsync(c->d_qdesc.p, qd_host.data(), qd_host.size() * sizeof(QDesc), hipMemcpyHostToDevice, c->stream_up));
-            HIP_TRY(hipStreamSynchronize(c->stream_up));
-            size_t off = 0;
             uint32_t bi = 0;
             for (auto &kv : batches) {
+                std::sort(kv.second.begin(), kv.second.end());          // (the order of the query table)
+                const size_t off = qdesc_off[kv.first];
                 const int T = kv.first.first, W = kv.first.second;
                 const uint32_t nqb = (uint32_t)kv.second.size();
                 DbPlan *dp = nullptr;
@@ -1304,21 +1538,34 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 uint64_t pass_sum = 0;
                 uint32_t max_p = 1;
                 for (uint32_t q : kv.second) { pass_sum += qps[q].passes; max_p = std::max<uint32_t>(max_p, qps[q].passes); }
-                hipStream_t st = (bi & 1) ? c->stream_b : c->stream;
-                DevBuf<uint2> &bnd = (bi & 1) ? c->d_bnd_b : c->d_bnd;
+                // (a database that streams in: three ranges in flight, each on a stream and a boundary scratch of its own --
+                // no tail kernels beside group-resident launches, so the tail stream serves as the third)
+                const uint32_t si = streaming ? (uint32_t)((bi + ri) % 3) : (bi & 1);
+                hipStream_t st = si == 0 ? c->stream : si == 1 ? c->stream_b : c->stream2;
+                DevBuf<uint2> &bnd = si == 0 ? c->d_bnd : si == 1 ? c->d_bnd_b : c->d_bnd_c;
                 if (run_resident_batch(c, main_mode, T, W, dp->main, c->d_qdesc.p + off, nqb, pass_sum, max_p, st, bnd)) return 1;
                 for (uint32_t q : kv.second) HIP_TRY(hipEventRecord(c->ev_query[2 * q], st));
-                off += nqb;
                 ++bi;
             }
             batches.clear();
         }
         // the next range's work lists need its geometry only: build them now, while the GPU aligns this range and
         // before the host blocks in the next range's copies
+        if (dbg && streaming) fprintf(stderr, "swimm_hip: range %zu: launches issued %.3f ms after the call began\n", ri, (now_s() - t_begin) * 1e3);
         if (streaming && ri + 1 < ranges.size())
             for (uint32_t q = 0; q < qn; ++q) { DbPlan *dp = nullptr; if (plan_of(ri + 1, q, &dp)) return 1; }
+        if (dbg && streaming) fprintf(stderr, "swimm_hip: range %zu: next range's work lists built %.3f ms after the call began\n", ri, (now_s() - t_begin) * 1e3);
     }
-    if (streaming && sync_lengths(c)) return 1;    // the promotion re-runs stop every alignment at its true length
+    if (streaming) {
+        // the ranges alternated between the two bulk streams: "query q's bulk kernels are done" = both have drained
+        HIP_TRY(hipEventRecord(c->ev_b, c->stream_b));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_b, 0));
+        HIP_TRY(hipEventRecord(c->ev_a, c->stream2));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_a, 0));
+        for (uint32_t q = 0; q < qn; ++q) HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
+        c->up->finish(false);
+        if (sync_lengths(c)) return 1;             // the promotion re-runs stop every alignment at its true length
+    }
     const double t_issued = now_s();
     // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
     // f16 results >= 2048 are re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; each
@@ -1422,6 +1669,11 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         HIP_TRY(hipEventElapsedTime(&lm, c->launch_ev[i], c->launch_ev[i + 1]));
         c->launch_ms_sum += lm;
         c->launch_ms_n++;
+        if (dbg) {
+            float at = 0;
+            (void)hipEventElapsedTime(&at, c->ev0, c->launch_ev[i]);
+            fprintf(stderr, "swimm_hip: pipeline launch %zu: starts %.3f ms after the search's first event, runs %.3f ms\n", i / 2, at, lm);
+        }
     }
     c->launch_ev_used = 0;
     if (dbg)
@@ -1514,8 +1766,10 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    delete c->up; c->up = nullptr;
     swimm_hip_clear_db(c);
-    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_qdesc.release();
+    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_qdesc.release();
+    if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = c->pin_used = 0; }
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_a.release(); c->tail_scratch_b.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1589,7 +1843,7 @@ int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint
     rec.first_seq = first_group * vl;
     rec.n_seq = (uint64_t)group_count * vl;
     if (register_chunk(c, rec, {})) return 1;
-    if (!c->opt_lazy_upload && upload_chunk(c, c->chunks.back())) return 1;
+    if (c->opt_lazy_upload ? ensure_uploader(c) : upload_chunk(c, c->chunks.back())) return 1;
     return 0;
 }
 
@@ -1619,7 +1873,7 @@ int swimm_hip_add_sequences(swimm_hip_ctx *c, const uint16_t *lengths, const cha
     rec.n_seq = n_seq;
     std::vector<uint32_t> lens(lengths, lengths + n_seq);
     if (register_chunk(c, rec, lens)) return 1;
-    if (!c->opt_lazy_upload && upload_chunk(c, c->chunks.back())) return 1;
+    if (c->opt_lazy_upload ? ensure_uploader(c) : upload_chunk(c, c->chunks.back())) return 1;
     return 0;
 }
 

@@ -217,6 +217,11 @@ struct swimm_hip_ctx {
     DevBuf<unsigned long long> d_stamps;   // diagnostic build only
     LaneScratch tail_scratch;           // lane kernel on stream 2 (long-sequence tail)
     LaneScratch tail_scratch_a, tail_scratch_b;   // one-pass queries that run whole on the main stream / on stream_b
+    // a search whose time is set by the long-sequence chains (a small database with one extreme sequence, many queries)
+    // runs up to three queries' tail launches side by side: two more streams (created on first use), scratch and events
+    hipStream_t stream_t[2] = {nullptr, nullptr};
+    hipEvent_t ev_tail_t[2] = {nullptr, nullptr};
+    LaneScratch tail_scratch_t[2];
     LaneScratch rerun_scratch;          // lane kernel on stream 3 (promotion re-runs)
     DevBuf<LaneItem> d_rerun_items;
     DevBuf<uint32_t> d_satlist;
@@ -1364,6 +1369,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     };
 
     if (dbg) fprintf(stderr, "swimm_hip: profile copy and score reset issued %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
+    int tail_lanes = 1;     // tail launches in flight at a time (decided with the buffer sizes below)
     // buffers that later launches grow are sized up front: a reallocation in the middle of the
     // multi-stream phase would free memory a kernel in flight still uses
     {
@@ -1426,6 +1432,29 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
         if (reserve_lane_scratch(c->tail_scratch, tail_cols, tail_items, max_passes)) return 1;
+        // How many queries' tail launches run side by side.  One, normally: the chains are a small part of the search
+        // and a second launch only takes registers from the bulk kernels (c3: -5 %).  But each query costs at least the
+        // longest sequence's chain (0.63 us per column with 8 rows per lane, 22 ms for 35 000 residues), whatever the
+        // size of the database: when those chains add up to more than the bulk work, up to three run at a time.
+        if (tail_items > 0 && !c->batch_now && !many_short) {
+            double chains = 0, rows = 0;
+            for (uint32_t q = 0; q < qn; ++q) {
+                const int lane_passes = (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows));
+                const int lr = (lane_passes == 1 && qm[q] <= 128 && c->opt_lane_rows) ? 2 : (lane_passes == 1 && qm[q] <= 256 && c->opt_lane_rows) ? 4 : kLaneRows;
+                chains += (double)longest_cols * 0.63e-6 * lr / kLaneRows * (lane_passes > 1 ? 1.1 : 1.0);
+                rows += qm[q];
+            }
+            const double bulk = rows * (double)c->total_cols * kGroupSeqs / 8000e9;
+            if (chains > 0.6 * bulk) tail_lanes = (int)std::min(3.0, std::ceil(chains / std::max(0.6 * bulk, 1e-6)));
+            if (dbg) fprintf(stderr, "swimm_hip: tail chains %.1f ms against %.1f ms of bulk work: %d tail launches at a time\n", chains * 1e3, bulk * 1e3, tail_lanes);
+        }
+        for (int i = 0; i + 1 < tail_lanes; ++i) {
+            if (!c->stream_t[i]) {
+                HIP_TRY(hipStreamCreate(&c->stream_t[i]));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_tail_t[i], hipEventDisableTiming));
+            }
+            if (reserve_lane_scratch(c->tail_scratch_t[i], tail_cols, tail_items, max_passes)) return 1;
+        }
         if (reserve_lane_scratch(c->tail_scratch_a, 0, tail_items, 1) || reserve_lane_scratch(c->tail_scratch_b, 0, tail_items, 1)) return 1;
         if (reserve_lane_scratch(c->rerun_scratch, (size_t)1 << 22, 4096, max_passes)) return 1;
         HIP_TRY(c->d_satlist.reserve((size_t)std::min<uint64_t>(S, 0xFFFFFFFEull) + 1));   // every slot could leave a tier's range
@@ -1437,8 +1466,9 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
+    for (int i = 0; i + 1 < tail_lanes; ++i) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], c->ev_ready, 0));
     HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_ready, 0));
-    uint32_t one_pass_seen = 0, multi_seen = 0;
+    uint32_t one_pass_seen = 0, multi_seen = 0, tail_seen = 0;
     HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
     while (c->ev_query.size() < 2 * (size_t)qn) {
         hipEvent_t e;
@@ -1474,6 +1504,7 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             HIP_TRY(hipStreamWaitEvent(c->stream, last.ready, 0));
             HIP_TRY(hipStreamWaitEvent(c->stream_b, last.ready, 0));
             HIP_TRY(hipStreamWaitEvent(c->stream2, last.ready, 0));
+            for (int i = 0; i + 1 < tail_lanes; ++i) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], last.ready, 0));
         }
         // Longest query first: its promotion re-runs (a handful of long serial chains on stream 3) then overlap
         // the bulk kernels of the shorter queries instead of running alone at the end.
@@ -1506,8 +1537,14 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
                 default: tail_stream = bulk_stream = c->stream2; break;
                 }
             }
+            if (tail_lanes > 1 && dp->tail.n > 0 && tail_stream == c->stream2) {      // chain-bound search: the tail launches take turns on up to three streams
+                const uint32_t ti = tail_seen++ % (uint32_t)tail_lanes;
+                if (ti > 0) { tail_stream = c->stream_t[ti - 1]; tail_scratch = &c->tail_scratch_t[ti - 1]; }
+            }
             DevBuf<uint2> *bnd = &c->d_bnd;
-            if (alternate && qps[q].passes > 1 && !rotated[q] && !qps[q].resident && (multi_seen++ & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
+            // (the one-pass queries of such a batch take their turn as well: they are the shortest, the batch ends with them,
+            // and a launch that runs alone ends with a few workgroups holding the chip -- c3's last eight queries: 26 ms at 5 900 GCUPS)
+            if (alternate && !rotated[q] && !qps[q].resident && !(many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows) && (multi_seen++ & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
             if (streaming && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
             if (!qps[q].resident && run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
             if (qps[q].resident) {      // every group goes into the group-resident launch of its shape, below
@@ -1655,6 +1692,10 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     }
     HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
+    for (int i = 0; i + 1 < tail_lanes; ++i) {
+        HIP_TRY(hipEventRecord(c->ev_tail_t[i], c->stream_t[i]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail_t[i], 0));
+    }
     HIP_TRY(hipEventRecord(c->ev_b, c->stream_b));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_b, 0));
     HIP_TRY(hipEventRecord(c->ev_tail3, c->stream3));
@@ -1770,7 +1811,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     swimm_hip_clear_db(c);
     c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_qdesc.release();
     if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = c->pin_used = 0; }
-    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_a.release(); c->tail_scratch_b.release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
+    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_a.release(); c->tail_scratch_b.release(); c->tail_scratch_t[0].release(); c->tail_scratch_t[1].release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
@@ -1782,6 +1823,10 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     for (hipEvent_t e : c->ev_query) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->launch_ev) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (int i = 0; i < 2; ++i) {
+        if (c->stream_t[i]) (void)hipStreamDestroy(c->stream_t[i]);
+        if (c->ev_tail_t[i]) (void)hipEventDestroy(c->ev_tail_t[i]);
+    }
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
     if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);

@@ -779,10 +779,14 @@ __device__ __forceinline__ void lane_prof_load(const unsigned char *q, uint32_t 
 // TR = query rows per lane: 8 (512 rows per pass, chained passes for longer queries); 4 and 2 for queries of up to 256 /
 // 128 rows, whose step -- a serial walk down the lane's rows -- is then that much shorter, and with it the time a
 // 35 000-residue sequence holds up a short query.
-template <bool PK, int TR>
+// M: 0 = packed int16 pairs, 1 = int32 (one sequence), 2 = packed binary16 pairs (the first tier of the long-sequence
+// tail: max3 makes a row 8.5 instead of 10 packed operations and its serial F chain three instead of four long;
+// alignments that reach 2048 are re-run in int16 by the promotion ladder, like the pipeline kernel's).
+template <int M, int TR>
 __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
 {
-    typedef typename std::conditional<PK, OpsPK, OpsI32>::type Ops;
+    constexpr bool PK = M != 1;
+    typedef typename std::conditional<M == 0, OpsPK, typename std::conditional<M == 1, OpsI32, OpsF16>::type>::type Ops;
     typedef typename Ops::V V;
     constexpr int C = kChunkCols, RP = 64 * TR, NW = TR / 2;   // NW dwords of profile per lane and residue
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -802,7 +806,12 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
         for (int idx = threadIdx.x; idx < kCodes * dw_per_code; idx += blockDim.x) {
             const int d = idx / dw_per_code, x = idx - d * dw_per_code;
             const uint32_t *src = (const uint32_t *)(p.prof + (size_t)d * p.prof_stride + r0);
-            *(uint32_t *)(smem + d * PS + x * 4) = src[x];
+            uint32_t v = src[x];
+            if (M == 2) {                           // int16 scores -> binary16
+                const v2s sv = as_v2s(v);
+                v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)sv.x, (_Float16)(float)sv.y});
+            }
+            *(uint32_t *)(smem + d * PS + x * 4) = v;
         }
     }
     __syncthreads();
@@ -811,7 +820,7 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     __builtin_amdgcn_s_setprio(2);
     const unsigned char *my_prof = smem + lane * TR * 2;
     const int last_lane = (int)((rows + TR - 1) / TR) - 1;      // lane holding the query's last rows in this pass
-    const V goe = Ops::splat(p.goe), ge = Ops::splat(p.ge);
+    const V goe = Ops::splat(M == 2 ? -p.goe : p.goe), ge = Ops::splat(M == 2 ? -p.ge : p.ge);
 
     V H[TR], E[TR];
 #pragma unroll
@@ -947,13 +956,12 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             diag = Ops::from_bits(Hin);
             V F = Ops::from_bits(Fin);
             const uint32_t *aw = acur;
-            if (PK) {
+            if constexpr (PK) {
                 const uint32_t *bw = bcur;
 #pragma unroll
-                for (int q = 0; q < NW; ++q) {
-                    cell<Ops>(hd, H[2 * q], E[2 * q], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)), goe, ge);
-                    cell<Ops>(hd, H[2 * q + 1], E[2 * q + 1], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
-                }
+                for (int q = 0; q < NW; ++q)
+                    cell2<Ops>(hd, H[2 * q], E[2 * q], H[2 * q + 1], E[2 * q + 1], F, best, Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
+                               Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
             } else {
 #pragma unroll
                 for (int q = 0; q < NW; ++q) {
@@ -968,7 +976,11 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
                 __hip_atomic_store(bnd_out + Cin, ((unsigned long long)oF << 32) | oH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine && (D & kFlagEnd)) {   // every pass contributes the best of its own rows
                 const LaneItem *iv = p.items + Sin;
-                if (PK) {
+                if (M == 2) {
+                    const v2h b2 = __builtin_bit_cast(v2h, oT);
+                    atomicMax(p.out + iv->slot_a, (int)(float)b2.x);
+                    atomicMax(p.out + iv->slot_b, (int)(float)b2.y);
+                } else if (PK) {
                     const v2s b2 = __builtin_bit_cast(v2s, oT);
                     atomicMax(p.out + iv->slot_a, (int)b2.x);
                     atomicMax(p.out + iv->slot_b, (int)b2.y);
@@ -995,8 +1007,9 @@ template <int TR>
 static hipError_t launch_lane_tr(Mode mode, int n_wg, const LaneParams &p, hipStream_t s)
 {
     const size_t lds = lane_lds_bytes(TR);
-    if (mode == Mode::PK16) hipLaunchKernelGGL((sw_lane_kernel<true, TR>), dim3(n_wg), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((sw_lane_kernel<false, TR>), dim3(n_wg), dim3(256), lds, s, p);
+    if (mode == Mode::PK16) hipLaunchKernelGGL((sw_lane_kernel<0, TR>), dim3(n_wg), dim3(256), lds, s, p);
+    else if (mode == Mode::F16) hipLaunchKernelGGL((sw_lane_kernel<2, TR>), dim3(n_wg), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((sw_lane_kernel<1, TR>), dim3(n_wg), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 

@@ -1546,7 +1546,9 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             // and a launch that runs alone ends with a few workgroups holding the chip -- c3's last eight queries: 26 ms at 5 900 GCUPS)
             if (alternate && !rotated[q] && !qps[q].resident && !(many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows) && (multi_seen++ & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
             if (streaming && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
-            if (!qps[q].resident && run_lane_passes(c, Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
+            // (the tail's first tier is the bulk's: binary16 pairs, unless that tier is switched off; the ladder below re-runs
+            // what reaches 2048 in int16 -- rare, the chains are long but the scores are not)
+            if (!qps[q].resident && run_lane_passes(c, main_mode == Mode::F16 ? Mode::F16 : Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
             if (qps[q].resident) {      // every group goes into the group-resident launch of its shape, below
                 if (dp->have_main) batches[std::make_pair(qps[q].T, qps[q].W)].push_back(q);
                 else HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));

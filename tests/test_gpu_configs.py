@@ -50,7 +50,17 @@ def test_c3_swissprot_shape_full_size():
         got, _ = s.search(chunks.vc * 128)
         st = s.last_stats()
         ts, ti, _ = s.search_topr(20, w["n"])
+        # the same database streamed in while it is searched (uploader thread, the end with the 35 000-residue sequence
+        # first, "long" judged against the whole database, a launch shape per range beside the tail kernels): .seq slabs
+        s.clear_db()
+        s.set_option("lazy_upload", 1)
+        offs = np.concatenate([[0], np.cumsum(w["lengths"].astype(np.int64))])
+        cuts = [0] + [int(x) // 128 * 128 for x in np.linspace(0, w["n"], 7)[1:-1]] + [w["n"]]
+        for s0, s1 in zip(cuts[:-1], cuts[1:]):
+            s.add_sequences(w["lengths"][s0:s1], w["codes"][offs[s0]:offs[s1]], first_seq=s0)
+        streamed, _ = s.search((w["n"] + 127) // 128 * 128)
     chunks.close()
+    assert np.array_equal(streamed[:, :w["n"]], got[:, :w["n"]])
     want, idx = oracle_matrix(w)
     _check_matrix(got[:, :w["n"]], want, idx, "c3")
     assert st["promoted"] >= 1                      # the planted copies of the long queries leave the int16 range (5478 x 5+)

@@ -184,7 +184,8 @@ def test_errors_are_loud():
             s.add_chunk(np.zeros(48, np.int8), np.array([1], np.uint16), np.array([0], np.uint32), 48, 0)
 
 
-@pytest.mark.parametrize("opts", [{}, {"tail_mode": 2}, {"tail_mode": 1}, {"dynamic": 0}, {"f16": 0, "bnd_mib": 1}, {"rows_per_wave": 16, "waves": 4}])
+@pytest.mark.parametrize("opts", [{}, {"tail_mode": 2}, {"tail_mode": 1}, {"dynamic": 0}, {"f16": 0, "bnd_mib": 1}, {"rows_per_wave": 16, "waves": 4},
+                                  {"resident": 0}, {"resident": 1}, {"resident": 0, "tail_mode": 2, "wg_limit": 8}])
 def test_streaming_upload_same_scores(tmp_path, golden, opts):
     """X2 overlapped with compute (MICsearch.c:85-91): with "lazy_upload" the chunks are copied and tiled while earlier
     chunks are being aligned, each chunk with work lists of its own.  Same golden scores with uploads in flight, in the

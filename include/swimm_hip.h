@@ -142,7 +142,9 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *   "lazy_upload"    0 = default: add_chunk / add_sequences copy the caller's buffers before they return; 1 = they only
  *                    record them and the next search streams the chunks in, copying and tiling chunk k+1 while chunk k
  *                    is being aligned (the double-buffered transfer of MICsearch.c:85-91) -- the buffers must then stay
- *                    valid until that search has returned.  swimm_hip_search_chunks always works this way.
+ *                    valid until that search has returned.  swimm_hip_search_chunks always works this way.  The copies
+ *                    are made by a thread the context owns (started with the first recorded chunk, parked between
+ *                    searches, joined by swimm_hip_destroy); the calls of one context still come from one thread at a time.
  *   "lane_acquire"   0 = default: chained lane-systolic passes read their predecessor's boundary rows with sc1 loads behind a
  *                    relaxed poll; 1 = an agent-scope acquire after every poll as well (A/B option)
  *   "score_mib"      HBM budget of the score rows (4 B per query and sequence): the query list is walked in batches

@@ -1110,33 +1110,115 @@ int sync_lengths(swimm_hip_ctx *c)
     return 0;
 }
 
-// device part of a search for the queries [qb, qe) (ascending-length order of set_queries): leaves exact scores in
+// Device part of a search for the queries [qb, qe) (ascending-length order of set_queries): leaves exact scores in
 // d_scores[(q - qb) * S + local_slot].  The callers walk the query list in batches whose score rows fit the
-// `score_mib` budget.
-int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_out)
+// `score_mib` budget.  One object per call; the phases run in the order of run().
+struct SearchRun {
+    swimm_hip_ctx *c;
+    uint32_t qb, qe, qn = 0;
+    bool dbg = false;
+    double t_begin = 0, t_sized = 0, t_issued = 0;
+    const uint16_t *qm = nullptr;           // the batch's query lengths / offsets into qcodes
+    const uint32_t *qdisp = nullptr;
+    uint64_t S = 0;                         // score slots per query
+    // the database: one range (resident, cached work lists) or the ranges a lazily uploaded database streams in as
+    bool streaming = false;
+    std::vector<Range> ranges;
+    std::vector<std::pair<size_t, size_t>> range_chunks;     // streaming: positions [first, last) in `up_order` of every range's chunks
+    std::vector<size_t> up_order;                            // streaming: the chunks in the order they travel
+    std::vector<std::map<int, DbPlan>> stream_plans;         // streaming: work lists per (range, workgroup count), released when the search has drained
+    // the launch plan
+    Mode main_mode = Mode::F16;
+    bool lane_room = false, many_short = false, alternate = false;
+    uint32_t longest_cols = 0;
+    std::vector<QueryPlan> qps;
+    std::vector<uint8_t> rotated;
+    std::vector<std::vector<QueryPlan>> rqps;                // streaming, per-pass launches: a launch shape per (range, query)
+    size_t prof_elems = 0;
+    int tail_lanes = 1;                     // tail launches in flight at a time (decided with the buffer sizes)
+
+    SearchRun(swimm_hip_ctx *ctx, uint32_t b, uint32_t e) : c(ctx), qb(b), qe(e) {}
+    ~SearchRun()
+    {
+        if (!streaming) return;
+        if (c->up) c->up->finish(true);          // (an early return: the chunks not yet copied stay where they are)
+        (void)hipDeviceSynchronize();
+        release_stream_plans();
+    }
+    void release_stream_plans()
+    {
+        for (auto &m : stream_plans) for (auto &kv : m) { kv.second.main.release(); kv.second.tail.release(); }
+        stream_plans.clear();
+    }
+    int wait_uploaded(size_t n)             // until the first n chunks of `up_order` are on their way
+    {
+        std::string err;
+        if (c->up->wait_issued(n, &err)) return fail("%s", err.empty() ? "upload failed" : err.c_str());
+        return 0;
+    }
+    const QueryPlan &qp_of(size_t ri, uint32_t q) const { return rqps.empty() ? qps[q] : rqps[ri][q]; }
+    int plan_of(size_t ri, uint32_t q, DbPlan **out);
+
+    int begin(uint64_t *slots_out);
+    int layout_ranges();
+    int plan_queries();
+    int upload_profiles();
+    int size_buffers();
+    int issue();
+    int promotion_ladder();
+    int drain();
+    int run(uint64_t *slots_out)
+    {
+        return begin(slots_out) || layout_ranges() || plan_queries() || upload_profiles() || size_buffers() || issue() || promotion_ladder() || drain();
+    }
+};
+
+// the work lists of a (range, launch shape): cached for the resident database, temporary for a streaming chunk
+int SearchRun::plan_of(size_t ri, uint32_t q, DbPlan **out)
+{
+    int per_cu = 1;
+    if (wgs_per_cu(c, main_mode, qp_of(ri, q).T, qp_of(ri, q).W, c->batch_now && !rotated[q], &per_cu)) return 1;
+    const int n_wg = n_workgroups(c, per_cu);
+    if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0 || qps[q].resident, out);
+    auto it = stream_plans[ri].find(n_wg);
+    if (it == stream_plans[ri].end()) {
+        DbPlan &dp = stream_plans[ri][n_wg];
+        bool exact = true;
+        for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[up_order[ci]].lens_known;
+        if (make_db_plan(c, main_mode, n_wg, qps[q].resident, ranges[ri], exact, dp)) return 1;
+        *out = &dp;
+    } else {
+        *out = &it->second;
+    }
+    return 0;
+}
+
+int SearchRun::begin(uint64_t *slots_out)
 {
     if (!c->have_queries) return fail("swimm_hip_search: no queries set");
     if (c->groups.empty()) return fail("swimm_hip_search: no database chunk resident");
     HIP_TRY(hipSetDevice(c->device));
     if (refresh_plans(c)) return 1;
-    const uint32_t qn = qe - qb;
-    const bool dbg = getenv("SWIMM_HIP_DEBUG") != nullptr;
-    const double t_begin = now_s();
-    const uint16_t *qm = c->qm.data() + qb;
-    const uint32_t *qdisp = c->qdisp.data() + qb;
-    const uint64_t S = (uint64_t)c->groups.size() * kGroupSeqs;
+    qn = qe - qb;
+    dbg = getenv("SWIMM_HIP_DEBUG") != nullptr;
+    t_begin = now_s();
+    qm = c->qm.data() + qb;
+    qdisp = c->qdisp.data() + qb;
+    S = (uint64_t)c->groups.size() * kGroupSeqs;
     *slots_out = S;
 
+    return 0;
+}
+
+int SearchRun::layout_ranges()
+{
     // Chunks whose bytes are still on the host (option "lazy_upload"): this search streams them in -- chunk k+1 is
     // copied and tiled on the upload stream while chunk k is being aligned (X2 overlapped with compute,
     // MICsearch.c:85-91) -- and every chunk is then one range with work lists of its own.  Otherwise the whole resident
     // database is one range with cached work lists.
-    bool streaming = false;
+    streaming = false;
     for (const ChunkRec &r : c->chunks) streaming = streaming || !r.uploaded;
     c->streaming_now = streaming;
-    std::vector<Range> ranges;
-    std::vector<std::pair<size_t, size_t>> range_chunks;     // streaming: positions [first, last) in `up_order` of every range's chunks
-    std::vector<size_t> up_order;                            // streaming: the chunks in the order they travel
     if (streaming) {
         uint64_t mb = 16, mn = 1, mg = 1, mo = 1;
         for (const ChunkRec &r : c->chunks) {
@@ -1190,45 +1272,34 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         if (ensure_uploader(c)) return 1;
         c->up->post(up_order);
     }
-    auto wait_uploaded = [&](size_t n) -> int {     // until the first n chunks of `up_order` are on their way
-        std::string err;
-        if (c->up->wait_issued(n, &err)) return fail("%s", err.empty() ? "upload failed" : err.c_str());
-        return 0;
-    };
-    std::vector<std::map<int, DbPlan>> stream_plans(streaming ? ranges.size() : 0);   // released when the search has drained
-    auto release_stream_plans = [&]() {
-        for (auto &m : stream_plans) for (auto &kv : m) { kv.second.main.release(); kv.second.tail.release(); }
-        stream_plans.clear();
-    };
-    struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{[&]() {
-        if (!streaming) return;
-        if (c->up) c->up->finish(true);          // (an early return: the chunks not yet copied stay where they are)
-        (void)hipDeviceSynchronize();
-        release_stream_plans();
-    }};
+    stream_plans.resize(streaming ? ranges.size() : 0);
+    return 0;
+}
 
+int SearchRun::plan_queries()
+{
     // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
     // query's end are zero, like the reference's dummy row 23
-    const Mode main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 ? Mode::F16 : Mode::PK16);
+    main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 ? Mode::F16 : Mode::PK16);
     // a database with a long-sequence tail is searched with launch shapes that leave room for lane-systolic waves
-    bool lane_room = false;
-    uint32_t longest_cols = 0;
+    lane_room = false;
+    longest_cols = 0;
     for (const GroupDesc &g : c->groups) longest_cols = std::max(longest_cols, g.ncols);
     if (c->opt_tail_mode != 2 && main_mode != Mode::I32)
         lane_room = c->opt_tail_mode == 1 || (double)longest_cols > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
     if (c->opt_lane_room >= 0) lane_room = c->opt_lane_room != 0 && main_mode != Mode::I32;
     if (dbg) fprintf(stderr, "swimm_hip: ranges laid out, uploader started %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
-    std::vector<QueryPlan> qps(qn);
-    std::vector<uint8_t> rotated(qn, 0);
+    qps.assign(qn, QueryPlan{});
+    rotated.assign(qn, 0);
     uint32_t n_short = 0;
     for (uint32_t q = 0; q < qn; ++q) n_short += qm[q] <= 64 * kLaneRows;
     // (with a handful of short queries the last ones' chains would stick out at the end of the search; and a database
     // with an extreme sequence -- c3's 35 000 residues are 6x a CU's mean load -- keeps the tail kernel, whose chain
     // is 3.6x faster per column than a 4-wave workgroup's)
-    const bool many_short = n_short >= 8 && !streaming;
+    many_short = n_short >= 8 && !streaming;
     const bool rotate = many_short && (double)longest_cols <= 2.0 * (double)c->total_cols / c->num_cu;
-    size_t prof_elems = 0;
+    prof_elems = 0;
     // Group-resident batch launches (option "resident"): the queries that are not rotated share ONE launch shape and run as one
     // launch whose items are (group, query) pairs.
     c->batch_now = false;
@@ -1292,7 +1363,6 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         // workgroup the per-pass launches with per-query shapes are 2-3 % ahead (c5 at 10 %: 8 470 vs 8 250 GCUPS)
         if (c->opt_resident < 0 && !streaming && c->groups.size() >= (size_t)16 * n_workgroups(c, per_cu)) c->batch_now = false;
     }
-    std::vector<std::vector<QueryPlan>> rqps;       // streaming, per-pass launches: a launch shape per (range, query)
     std::vector<BulkCols> rbulk;
     if (streaming && !c->batch_now && ranges.size() > 1) {
         rqps.assign(ranges.size(), std::vector<QueryPlan>(qn));
@@ -1326,7 +1396,12 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     // the other query.  (Within ONE such query the even/odd split of run_passes does the same.)
     uint32_t n_multi = 0;
     for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && qps[q].passes > 1;
-    const bool alternate = n_multi >= 2 && c->opt_alternate && !streaming;
+    alternate = n_multi >= 2 && c->opt_alternate && !streaming;
+    return 0;
+}
+
+int SearchRun::upload_profiles()
+{
     std::vector<int16_t> prof(prof_elems, 0);
     for (uint32_t q = 0; q < qn; ++q) {
         const int8_t *qa = c->qcodes.data() + qdisp[q];
@@ -1342,34 +1417,20 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             rv[q].mpad = qps[q].mpad; rv[q].prof_off = qps[q].prof_off;      // one profile per query, padded for the tallest plan
             rv[q].mode = main_mode; rv[q].dynamic = qps[q].dynamic; rv[q].resident = false;
         }
-    auto qp_of = [&](size_t ri, uint32_t q) -> const QueryPlan & { return rqps.empty() ? qps[q] : rqps[ri][q]; };
     if (dbg) fprintf(stderr, "swimm_hip: launch shapes chosen and profiles built %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_scores.reserve((size_t)qn * S));
     HIP_TRY(hipMemsetAsync(c->d_scores.p, 0, (size_t)qn * S * sizeof(int32_t), c->stream));
 
-    // the work lists of a (range, launch shape): cached for the resident database, temporary for a streaming chunk
-    auto plan_of = [&](size_t ri, uint32_t q, DbPlan **out) -> int {
-        int per_cu = 1;
-        if (wgs_per_cu(c, main_mode, qp_of(ri, q).T, qp_of(ri, q).W, c->batch_now && !rotated[q], &per_cu)) return 1;
-        const int n_wg = n_workgroups(c, per_cu);
-        if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0 || qps[q].resident, out);
-        auto it = stream_plans[ri].find(n_wg);
-        if (it == stream_plans[ri].end()) {
-            DbPlan &dp = stream_plans[ri][n_wg];
-            bool exact = true;
-            for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[up_order[ci]].lens_known;
-            if (make_db_plan(c, main_mode, n_wg, qps[q].resident, ranges[ri], exact, dp)) return 1;
-            *out = &dp;
-        } else {
-            *out = &it->second;
-        }
-        return 0;
-    };
+    return 0;
+}
+
+int SearchRun::size_buffers()
+{
 
     if (dbg) fprintf(stderr, "swimm_hip: profile copy and score reset issued %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
-    int tail_lanes = 1;     // tail launches in flight at a time (decided with the buffer sizes below)
+    tail_lanes = 1;
     // buffers that later launches grow are sized up front: a reallocation in the middle of the
     // multi-stream phase would free memory a kernel in flight still uses
     {
@@ -1460,7 +1521,12 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         HIP_TRY(c->d_satlist.reserve((size_t)std::min<uint64_t>(S, 0xFFFFFFFEull) + 1));   // every slot could leave a tier's range
         HIP_TRY(c->d_rerun_items.reserve(4096));
     }
-    const double t_sized = now_s();
+    return 0;
+}
+
+int SearchRun::issue()
+{
+    t_sized = now_s();
     HIP_TRY(c->d_err.reserve(1));
     HIP_TRY(hipMemsetAsync(c->d_err.p, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -1605,7 +1671,12 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
         c->up->finish(false);
         if (sync_lengths(c)) return 1;             // the promotion re-runs stop every alignment at its true length
     }
-    const double t_issued = now_s();
+    return 0;
+}
+
+int SearchRun::promotion_ladder()
+{
+    t_issued = now_s();
     // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
     // f16 results >= 2048 are re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; each
     // re-run is a lane-systolic item (one wave per alignment), issued on stream 3 as soon as the query's own
@@ -1692,6 +1763,11 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
             if (rerun(q, Mode::I32, items)) return 1;
         }
     }
+    return 0;
+}
+
+int SearchRun::drain()
+{
     HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
     for (int i = 0; i + 1 < tail_lanes; ++i) {
@@ -1727,6 +1803,12 @@ int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_ou
     if (werr) return fail("pipeline watchdog expired (code %u): results discarded", werr);
     if (streaming) { release_plans(c); c->groups_dirty = true; }   // (the cached lists of the resident database are built on the next search)
     return 0;
+}
+
+int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_out)
+{
+    SearchRun run(c, qb, qe);
+    return run.run(slots_out);
 }
 
 }  // namespace

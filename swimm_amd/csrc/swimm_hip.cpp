@@ -367,17 +367,18 @@ double plan_imbalance(swimm_hip_ctx *c, int n_wg)
 
 // Measured throughput (GCUPS of padded cells) of every launch shape of the f16-tier pipeline kernel: rows per wave
 // T = 8, 12, ... 36 (lines) by waves per workgroup W = 1..16 (columns), workgroups per CU by occupancy
-// (tools/plan_sweep.py on one MI355X, profiles/r01_plan_sweep.txt).  W = 4, 8, 12, 16 put the same number of waves
+// (tools/plan_sweep.py --scale 1.0 on one MI355X, profiles/r02_plan_sweep.txt; round 1's table, before the next-chunk
+// prefetch, was 2-5 % lower and had the 8-wave shapes a little further behind the 4-wave ones).  W = 4, 8, 12, 16 put the same number of waves
 // on each of the CU's 4 SIMDs; any other W runs like the next multiple of 4 (2 x 6 waves behave like 4+4+2+2).
 static const float kShapeGcups[8][16] = {
-    {2266, 3928, 4832, 6058, 5717, 6894, 7079, 7660, 7008, 5520, 6739, 7313, 6811, 6748, 5836, 7562},     // T=8
-    {2809, 4488, 5797, 7254, 6593, 7065, 7299, 8107, 7423, 6014, 7321, 7880, 7264, 7154, 7618, 8065},     // T=12
-    {3222, 5019, 6511, 7937, 5774, 5152, 7068, 8043, 5267, 5854, 6438, 6983, 6022, 6494, 6932, 7386},     // T=16
-    {3404, 5399, 6923, 8094, 4988, 5536, 7173, 8149, 5500, 6097, 6699, 7307, 6114, 6728, 7189, 7666},     // T=20
-    {3718, 5836, 7306, 8342, 5485, 6312, 7257, 8171, 5661, 6295, 6900, 7530, 6338, 6886, 7357, 7858},     // T=24
-    {3798, 5878, 7162, 8368, 6168, 6278, 7274, 8263, 5791, 6432, 7064, 7698, 6514, 7005, 7500, 8004},     // T=28
-    {3788, 6116, 6238, 8438, 4572, 5507, 6388, 7272, 5864, 6525, 7183, 7806, 0, 0, 0, 0},                 // T=32
-    {3929, 6424, 5650, 8514, 4674, 5601, 6434, 7430, 5960, 6630, 7001, 7931, 0, 0, 0, 0},                 // T=36
+    {2648, 4406, 5432, 6668, 6283, 6811, 7102, 7832, 6982, 6376, 6976, 7578, 6850, 6875, 5896, 7802},  // T=8
+    {3154, 4918, 6308, 7339, 6506, 6819, 7204, 8185, 7142, 6730, 7484, 8118, 7147, 7256, 7739, 8158},  // T=12
+    {3700, 5675, 6768, 8168, 6496, 5518, 7106, 8065, 5692, 6337, 6946, 7561, 6327, 6795, 7255, 7723},  // T=16
+    {3895, 5893, 6987, 8264, 5406, 6190, 7304, 8334, 5795, 6487, 7105, 7776, 6269, 7035, 7535, 8037},  // T=20
+    {4050, 6271, 7188, 8332, 5487, 6435, 7450, 8474, 5890, 6645, 7222, 7935, 6429, 7149, 7621, 8150},  // T=24
+    {4161, 6397, 7264, 8398, 6255, 6469, 7553, 8609, 6052, 6740, 7383, 8061, 6722, 7229, 7752, 8263},  // T=28
+    {4130, 6470, 6405, 8592, 4870, 5827, 6764, 7683, 6120, 6796, 7444, 8120, 0, 0, 0, 0},                 // T=32
+    {4144, 6660, 6398, 8523, 4902, 5900, 6674, 7809, 6154, 6874, 7083, 8217, 0, 0, 0, 0},                 // T=36
 };
 
 // Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the shape with the lowest

@@ -134,6 +134,8 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    touches (no launch boundary; measured equal to the default within 1 %)
  *   "lane_room"      -1 = default: launch shapes leave a lane-systolic wave its registers when the database has a long-sequence
  *                    tail; 0 = never; 1 = always
+ *   "rotate"         1 = default: when no group-resident batch is formed, eight or more one-pass queries run whole on three
+ *                    streams in rotation; 0 = one stream
  *   "alternate"      1 = default: in a batch with two or more multi-pass queries, consecutive queries run their passes on two
  *                    streams, so that the end of every launch is covered by a kernel of the other query; 0 = one stream
  *   "split"          1 = default: a query of three or more passes runs the even- and odd-ranked groups as two kernels on two streams,

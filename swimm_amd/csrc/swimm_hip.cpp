@@ -176,6 +176,7 @@ struct swimm_hip_ctx {
     size_t launch_ev_used = 0;
     double launch_ms_sum = 0;           // sum of the pipeline launches' own durations in the last search
     uint32_t launch_ms_n = 0;
+    int opt_rotate = 1;                 // 1: eight or more one-pass queries run whole on three streams in rotation; 0: they join the group-resident batch
     int opt_alternate = 1;              // 1: the passes of consecutive multi-pass queries alternate between two streams
     int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
     int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
@@ -454,30 +455,46 @@ static uint64_t prof_elems_bound(const uint16_t *qm, uint32_t qn)
     return n;
 }
 
-// One launch shape for a whole batch of queries (group-resident launches take all queries of one shape in one launch): the
-// 4-wave shapes only -- measured (profiles/r02_ab_batch.txt), the group-resident kernel equals the per-pass kernel with 4-wave
-// workgroups and loses 9 % with 8 -- and the rows per wave that waste the fewest padded rows over the batch at that shape's rate.
-int choose_batch_shape(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, const std::vector<uint8_t> &rotated, uint32_t qn, bool room_for_lane_waves, int *T_out, int *W_out)
+// The launch shapes of a group-resident batch (all queries of a shape run in one launch): the 4-wave shapes only --
+// measured (profiles/r02_ab_batch.txt), the group-resident kernel equals the per-pass kernel with 4-wave workgroups and
+// loses 9 % with 8.  First the shape that wastes the fewest padded rows over the whole batch at that shape's rate; a
+// query leaves it for a shape of its own only when that saves more than 12 % of its time (short queries: 96 instead of 128
+// rows), because every further shape is a further launch with an end of its own (60 queries of 1 200-1 400 residues:
+// 8 270 GCUPS in one launch, 8 010 in four).
+int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_t qn, std::vector<QueryPlan> &qps)
 {
-    double best = -1;
+    double cost[8] = {};
+    int Wof[8] = {};
+    bool ok[8] = {};
+    auto rows_of = [](int m, int T, int W) { return (double)((m + T * W - 1) / (T * W)) * T * W; };
     for (int ti = 7; ti >= 0; --ti) {
         const int T = 8 + 4 * ti;
         if (c->opt_T && T != c->opt_T) continue;
         if (!pipe_has_variant(mode, T)) continue;
         if (T == 28 && !c->opt_T) continue;                       // the group-resident 28-row kernel does not fit 128 VGPRs
-        const int W = c->opt_W > 0 ? std::min(c->opt_W, T > 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
-        int per_cu = 1, regs = 0;
-        if (wgs_per_cu(c, mode, T, W, true, &per_cu) || kernel_regs(c, mode, T, true, &regs)) return 1;
-        if (room_for_lane_waves && !c->opt_T && ((regs + 7) / 8 * 8) * ((per_cu * W + 3) / 4) > 512 - 80) continue;
-        double rows = 0;
-        for (uint32_t q = 0; q < qn; ++q)
-            if (!rotated[q]) rows += (double)((qm[q] + T * W - 1) / (T * W)) * T * W;
-        const double cost = rows / kShapeGcups[ti][W - 1];
-        if (getenv("SWIMM_HIP_DEBUG")) fprintf(stderr, "swimm_hip: batch shape %d x %d: %.0f padded rows / %.0f GCUPS = %.3f (%d workgroups per CU, %d VGPRs)\n", W, T, rows, (double)kShapeGcups[ti][W - 1], cost, per_cu, regs);
-        if (best < 0 || cost < best) { best = cost; *T_out = T; *W_out = W; }
+        Wof[ti] = c->opt_W > 0 ? std::min(c->opt_W, T > 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
+        ok[ti] = true;
+        for (uint32_t q = 0; q < qn; ++q) cost[ti] += rows_of(qm[q], T, Wof[ti]) / kShapeGcups[ti][Wof[ti] - 1];
     }
-    if (best < 0 && room_for_lane_waves) return choose_batch_shape(c, mode, qm, rotated, qn, false, T_out, W_out);
-    if (best < 0) return fail("no group-resident kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W);
+    int common = -1;
+    for (int ti = 7; ti >= 0; --ti)
+        if (ok[ti] && (common < 0 || cost[ti] < cost[common])) common = ti;
+    if (common < 0) return fail("no group-resident kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W);
+    for (uint32_t q = 0; q < qn; ++q) {
+        int pick = common;
+        const double cc = rows_of(qm[q], 8 + 4 * common, Wof[common]) / kShapeGcups[common][Wof[common] - 1];
+        double bc = cc;
+        for (int ti = 7; ti >= 0; --ti) {
+            if (!ok[ti]) continue;
+            const double x = rows_of(qm[q], 8 + 4 * ti, Wof[ti]) / kShapeGcups[ti][Wof[ti] - 1];
+            if (x < 0.88 * cc && x < bc) { bc = x; pick = ti; }
+        }
+        QueryPlan &qp = qps[q];
+        qp.T = 8 + 4 * pick; qp.W = Wof[pick];
+        const int strips = std::max(1, (qm[q] + qp.T - 1) / qp.T);
+        qp.passes = (strips + qp.W - 1) / qp.W;
+        qp.mpad = (uint32_t)(qp.passes * qp.W * qp.T);
+    }
     return 0;
 }
 
@@ -1299,41 +1316,16 @@ int SearchRun::plan_queries()
     // with an extreme sequence -- c3's 35 000 residues are 6x a CU's mean load -- keeps the tail kernel, whose chain
     // is 3.6x faster per column than a 4-wave workgroup's)
     many_short = n_short >= 8 && !streaming;
-    const bool rotate = many_short && (double)longest_cols <= 2.0 * (double)c->total_cols / c->num_cu;
+    const bool rotate = many_short && c->opt_rotate && (double)longest_cols <= 2.0 * (double)c->total_cols / c->num_cu;
     prof_elems = 0;
-    // Group-resident batch launches (option "resident"): the queries that are not rotated share ONE launch shape and run as one
-    // launch whose items are (group, query) pairs.
-    c->batch_now = false;
-    {
-        uint32_t non_rot = 0;
-        for (uint32_t q = 0; q < qn; ++q) non_rot += !(rotate && qm[q] <= 64 * kLaneRows);
-        c->batch_now = c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && (non_rot >= 2 || streaming)));
-    }
-    for (uint32_t q = 0; q < qn; ++q) {
-        // Eight or more short queries in the batch: those that fit one pass run whole -- every group through the
-        // pipeline kernel, no tail kernel -- on three streams in rotation (below); a long sequence's serial chain,
-        // which bounds a lone short query, is then covered by the neighbours' work.
-        rotated[q] = 0;
-        if (rotate && qm[q] <= 64 * kLaneRows) {
-            c->batch_now = false;                 // (rotated queries run the per-pass kernel: plan them with its registers)
-            rotated[q] = choose_plan(c, main_mode, qm[q], false, true, &qps[q]) == 0;   // fails when no one-pass shape exists
-        }
-    }
-    {
-        uint32_t non_rot = 0;
-        for (uint32_t q = 0; q < qn; ++q) non_rot += !rotated[q];
-        // (a database that is streaming in is aligned range by range: there even a single query runs group-resident, one launch
-        // per range instead of one per range and pass)
-        c->batch_now = c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && (non_rot >= 2 || streaming))) && non_rot > 0;
-    }
-    if ((uint64_t)qn * S > 0xFFFFFFFFull || prof_elems_bound(qm, qn) > 0xFFFFFFFFull) c->batch_now = false;   // (a batch addresses score rows and profiles with 32-bit offsets)
-    int batch_T = 0, batch_W = 0;
+    // Group-resident batch launches (option "resident"): ONE launch per launch shape whose items are (group, query) pairs.
+    // Every query gets the 4-wave shape that wastes the fewest padded rows at that shape's rate, and the queries of a shape
+    // run together -- short one-pass queries included: a batch is the better home for them than the rotation below (300
+    // queries of 80-120 residues against 1e8: 6 290 -> 6 600 GCUPS with one shape for all, more with a shape per query).
+    c->batch_now = c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && (qn >= 2 || streaming))) &&
+                   !((uint64_t)qn * S > 0xFFFFFFFFull || prof_elems_bound(qm, qn) > 0xFFFFFFFFull);   // (a batch addresses score rows and profiles with 32-bit offsets)
     // (no register room is reserved for the lane-systolic waves here: among the 4-wave shapes only the 8-row one would pass that
-    // filter, at 6 000 instead of 8 400 GCUPS; the tail kernels are launched first and get their slots, the batch launch's
-    // workgroups that do not fit beside them start when they are done)
-    if (dbg) fprintf(stderr, "swimm_hip: rotation decided %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
-    if (c->batch_now && choose_batch_shape(c, main_mode, qm, rotated, qn, false, &batch_T, &batch_W)) return 1;
-    if (dbg) fprintf(stderr, "swimm_hip: batch shape chosen %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
+    // filter, at 6 000 instead of 8 400 GCUPS)
     if (c->batch_now) {
         // A batch launch is one persistent kernel for the whole batch: lane-systolic tail kernels launched beside it would
         // find no free slot until it ends (measured: c3 -16 %, a 1e8-residue database -25 %).  So a batch takes EVERY group
@@ -1341,19 +1333,20 @@ int SearchRun::plan_queries()
         // longest query; the queue hands it out first) is at most half a workgroup's share of the batch; otherwise (c3: a
         // 35 000-residue sequence is 2.3 shares) the batch is not formed and the queries run one launch per pass beside their
         // tail kernels.
-        double pass_sum = 0;
+        double share = 0;
         uint32_t max_passes = 1;
-        for (uint32_t q = 0; q < qn; ++q)
-            if (!rotated[q]) {
-                const uint32_t ps = (uint32_t)(((qm[q] + batch_T - 1) / batch_T + batch_W - 1) / batch_W);
-                pass_sum += ps; max_passes = std::max(max_passes, ps);
-            }
-        int per_cu = 1;
-        if (wgs_per_cu(c, main_mode, batch_T, batch_W, true, &per_cu)) return 1;
-        const double share = pass_sum * (double)c->total_cols / n_workgroups(c, per_cu);
+        int most_wg = 1;
+        if (choose_batch_shapes(c, main_mode, qm, qn, qps)) return 1;
+        for (uint32_t q = 0; q < qn; ++q) {
+            int per_cu = 1;
+            if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, true, &per_cu)) return 1;
+            share += (double)qps[q].passes * (double)c->total_cols / n_workgroups(c, per_cu);
+            max_passes = std::max<uint32_t>(max_passes, (uint32_t)qps[q].passes);
+            most_wg = std::max(most_wg, n_workgroups(c, per_cu));
+        }
         if (dbg)
-            fprintf(stderr, "swimm_hip: batch of %.0f passes, shape %d x %d: longest item %u columns x %u passes, a workgroup's share %.0f column-passes, %zu groups for %d workgroups\n",
-                    pass_sum, batch_W, batch_T, longest_cols, max_passes, share, c->groups.size(), n_workgroups(c, per_cu));
+            fprintf(stderr, "swimm_hip: batch of %u queries: longest item %u columns x %u passes, a workgroup's share %.0f column-passes, %zu groups for up to %d workgroups\n",
+                    qn, longest_cols, max_passes, share, c->groups.size(), most_wg);
         // (a database that streams in as several ranges: consecutive ranges overlap on two streams, the long items travel
         // and start first, and the last range is the one with the short sequences -- the longest item may take 0.9 of
         // the whole search before it sticks out at the end)
@@ -1362,8 +1355,15 @@ int SearchRun::plan_queries()
         // ... and it pays on a database that is small for the chip: with few groups per workgroup every per-pass launch fills and
         // drains its pipelines for two or three items and ends unbalanced (1e8 residues: +13-15 %); with dozens of groups per
         // workgroup the per-pass launches with per-query shapes are 2-3 % ahead (c5 at 10 %: 8 470 vs 8 250 GCUPS)
-        if (c->opt_resident < 0 && !streaming && c->groups.size() >= (size_t)16 * n_workgroups(c, per_cu)) c->batch_now = false;
+        if (c->opt_resident < 0 && !streaming && c->groups.size() >= (size_t)16 * most_wg) c->batch_now = false;
     }
+    if (dbg) fprintf(stderr, "swimm_hip: batch decided %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
+    // No batch, eight or more short queries: those that fit one pass run whole -- every group through the pipeline kernel,
+    // no tail kernel -- on three streams in rotation (issue()); a long sequence's serial chain, which bounds a lone short
+    // query, is then covered by the neighbours' work.
+    if (!c->batch_now && rotate)
+        for (uint32_t q = 0; q < qn; ++q)
+            if (qm[q] <= 64 * kLaneRows) rotated[q] = choose_plan(c, main_mode, qm[q], false, true, &qps[q]) == 0;   // fails when no one-pass shape exists
     std::vector<BulkCols> rbulk;
     if (streaming && !c->batch_now && ranges.size() > 1) {
         rqps.assign(ranges.size(), std::vector<QueryPlan>(qn));
@@ -1371,11 +1371,7 @@ int SearchRun::plan_queries()
         for (size_t ri = 0; ri < ranges.size(); ++ri) bulk_cols_of(c, ranges[ri], rbulk[ri]);
     }
     for (uint32_t q = 0; q < qn; ++q) {
-        if (!rotated[q] && c->batch_now) {
-            const int strips = std::max(1, (qm[q] + batch_T - 1) / batch_T);
-            qps[q].T = batch_T; qps[q].W = batch_W; qps[q].passes = (strips + batch_W - 1) / batch_W;
-            qps[q].mpad = (uint32_t)(qps[q].passes * batch_W * batch_T);
-        } else if (!rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;
+        if (!c->batch_now && !rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;   // (a batch's shapes are chosen above)
         if (dbg)
             fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
         // A database that is streaming in, per-pass launches: every range gets the launch shape that suits ITS groups -- the
@@ -2208,6 +2204,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         if (value < 1 || value > 1000) return fail("tail_frac must be 1..1000 (percent of a CU's mean load)");
         c->opt_tail_frac = value;
         release_plans(c);
+    } else if (!strcmp(key, "rotate")) {
+        c->opt_rotate = value != 0;
     } else if (!strcmp(key, "lane_rows")) {
         c->opt_lane_rows = value != 0;
     } else if (!strcmp(key, "lane_room")) {

@@ -202,6 +202,11 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
+    # stdout carries the ONE JSON line and nothing else: whatever the libraries print there (gloo's connection notes, ...)
+    # goes to stderr from here on
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -471,7 +476,7 @@ def main():
             out["cpu_baseline"] = {"value": round(q_real * res_s / cpu_s / 1e9, 2), "unit": "GCUPS", "cores": cores_all, "threads": my_threads,
                                    "kind": kind, "cpu_model": model, "matches_gpu": ok,
                                    "sample": f"{args.workload} shard, every {stride}th sequence ({n_s} sequences, {res_s} residues), {nq} quer{'y' if nq == 1 else 'ies'}, {cpu_s:.2f} s"}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     searcher.close()
     if chunks is not None:
         chunks.close()

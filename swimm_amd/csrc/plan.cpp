@@ -1,0 +1,485 @@
+// plan.cpp -- launch plans (rows per wave, waves, passes from the measured rate table and the longest-first
+// makespan) and the work lists of the persistent workgroups / the lane-systolic tail.
+#include "swimm_impl.h"
+
+namespace swimm_impl {
+
+Range whole_range(const swimm_hip_ctx *c) { Range r; r.g0 = 0; r.g1 = (uint32_t)c->groups.size(); r.cols = c->total_cols; return r; }
+
+void release_plans(swimm_hip_ctx *c)
+{
+    for (auto &kv : c->plans) { kv.second.main.release(); kv.second.tail.release(); }
+    c->plans.clear();
+    c->bulk.cols.clear(); c->bulk.total = 0; c->bulk.cache.clear();
+}
+
+int regs_to_waves_per_simd(int regs)
+{
+    const int alloc = (regs + 7) / 8 * 8;   // MI355X_MICROARCH: 8-register granule, 512 per SIMD lane
+    return std::max(1, std::min(8, 512 / std::max(alloc, 8)));
+}
+
+// how many workgroups of W waves of the T-row kernel one CU holds (VGPRs: 8-register granule, 512 per SIMD
+// lane; LDS: 160 KiB)
+int kernel_regs(const swimm_hip_ctx *c, Mode mode, int T, bool resident, int *out)
+{
+    int &regs = const_cast<swimm_hip_ctx *>(c)->regs_cache[resident ? 1 : 0][(int)mode][T];
+    if (regs == 0) HIP_TRY(pipe_kernel_attributes(mode, T, resident, &regs));
+    *out = regs;
+    return 0;
+}
+
+int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, bool resident, int *out)
+{
+    int regs = 0;
+    if (kernel_regs(c, mode, T, resident, &regs)) return 1;
+    const int waves_cu = 4 * regs_to_waves_per_simd(regs);
+    const size_t lds = pipe_lds_bytes(T, W, resident);
+    int n = std::min(waves_cu / W, (int)(163840 / lds));
+    if (c->opt_wgs_per_cu > 0) n = c->opt_wgs_per_cu;
+    *out = std::max(1, n);
+    return 0;
+}
+
+// a query of several passes runs the group-resident kernel (one launch) unless that is switched off
+bool resident_for(const swimm_hip_ctx *c, int passes) { (void)passes; return c->batch_now; }
+
+// a run of consecutive device groups that is searched as one unit: the whole resident database (work lists cached),
+// or one chunk of a database that is still streaming in
+// Work lists travel on the upload stream -- except while a search streams its database in: the upload stream then
+// belongs to the uploader thread's chunk copies (0.1 GB each), and the lists take the promotion stream, idle until
+// the ladder at the end of the search.
+hipStream_t list_stream(const swimm_hip_ctx *c) { return c->streaming_now ? c->stream3 : c->stream_up; }
+
+// ... and through a pinned arena: a copy from pageable memory would queue for the runtime's staging buffers behind
+// the uploader's chunk copies (measured: 1.2 ms per range's lists instead of 0.3).  list_sync() ends a batch of copies.
+int list_copy(swimm_hip_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    if (c->pin_used + bytes > c->pin_cap) {
+        HIP_TRY(hipStreamSynchronize(list_stream(c)));        // copies in flight still read the arena
+        c->pin_used = 0;
+        if (bytes > c->pin_cap) {
+            if (c->pin) { HIP_TRY(hipHostFree(c->pin)); c->pin = nullptr; c->pin_cap = 0; }
+            const size_t cap = std::max<size_t>(2 * bytes, (size_t)4 << 20);
+            HIP_TRY(hipHostMalloc(&c->pin, cap, hipHostMallocDefault));
+            c->pin_cap = cap;
+        }
+    }
+    char *at = (char *)c->pin + c->pin_used;
+    memcpy(at, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, list_stream(c)));
+    c->pin_used += (bytes + 255) & ~(size_t)255;
+    return 0;
+}
+int list_sync(swimm_hip_ctx *c)
+{
+    HIP_TRY(hipStreamSynchronize(list_stream(c)));
+    c->pin_used = 0;
+    return 0;
+}
+
+
+// persistent workgroups of a pipeline launch: what the chip holds, unless the caller caps it
+int n_workgroups(const swimm_hip_ctx *c, int per_cu)
+{
+    const int n = c->num_cu * per_cu;
+    return c->opt_wg_limit > 0 ? std::min(n, c->opt_wg_limit) : n;
+}
+
+// How evenly the bulk groups of the resident database spread over n_wg workgroups: makespan of the longest-first
+// greedy schedule (what the dynamic queue, and the static partition, produce) over the mean load.  1.00x for a
+// large database; a small one whose longest group is a sizeable part of a workgroup's share reaches 1.4 - 1.9
+// with 3 - 4 workgroups per CU, and then fewer, larger workgroups are the better launch shape.
+double lpt_imbalance(BulkCols &b, int n_wg)
+{
+    auto it = b.cache.find(n_wg);
+    if (it != b.cache.end()) return it->second;
+    const std::vector<uint32_t> &cols = b.cols;
+    const uint64_t total = b.total;
+    double r = 1.0;
+    if (!cols.empty() && total > 0) {
+        const int n = std::max(1, std::min<int>(n_wg, (int)cols.size()));
+        // Longest-first greedy.  With many groups per workgroup the schedule ends within one short group of the mean
+        // load; the exact simulation only matters (and is only run) while a workgroup gets fewer than 64 groups.
+        if (cols.size() >= (size_t)64 * n) {
+            const double mean = (double)total / n_wg;
+            r = std::max((double)cols[0], mean + 0.5 * cols[cols.size() - cols.size() / 8 - 1]) / mean;
+        } else {
+            std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> heap;
+            for (int w = 0; w < n; ++w) heap.push(0);
+            uint64_t mx = 0;
+            for (uint32_t x : cols) { uint64_t l = heap.top() + x; heap.pop(); heap.push(l); mx = std::max(mx, l); }
+            r = (double)mx / ((double)total / n_wg);   // fewer groups than workgroups: the idle ones count
+        }
+    }
+    b.cache[n_wg] = r;
+    return r;
+}
+
+// the bulk groups of a range (those the tail picker leaves to the pipeline kernel), longest first
+void bulk_cols_of(const swimm_hip_ctx *c, const Range &rg, BulkCols &b)
+{
+    const std::vector<uint8_t> is_tail = pick_tail(c, rg);
+    b.cols.clear(); b.total = 0; b.cache.clear();
+    for (uint32_t g = rg.g0; g < rg.g1; ++g)
+        if (!is_tail[g - rg.g0]) { b.cols.push_back(c->groups[g].ncols); b.total += c->groups[g].ncols; }
+    std::sort(b.cols.begin(), b.cols.end(), std::greater<uint32_t>());
+}
+
+double plan_imbalance(swimm_hip_ctx *c, int n_wg)
+{
+    if (c->bulk.cols.empty() && !c->groups.empty()) bulk_cols_of(c, whole_range(c), c->bulk);     // once per database
+    return lpt_imbalance(c->bulk, n_wg);
+}
+
+// Measured throughput (GCUPS of padded cells) of every launch shape of the f16-tier pipeline kernel: rows per wave
+// T = 8, 12, ... 36 (lines) by waves per workgroup W = 1..16 (columns), workgroups per CU by occupancy
+// (tools/plan_sweep.py --scale 1.0 on one MI355X, profiles/r02_plan_sweep.txt; round 1's table, before the next-chunk
+// prefetch, was 2-5 % lower and had the 8-wave shapes a little further behind the 4-wave ones).  W = 4, 8, 12, 16 put the same number of waves
+// on each of the CU's 4 SIMDs; any other W runs like the next multiple of 4 (2 x 6 waves behave like 4+4+2+2).
+static const float kShapeGcups[8][16] = {
+    {2648, 4406, 5432, 6668, 6283, 6811, 7102, 7832, 6982, 6376, 6976, 7578, 6850, 6875, 5896, 7802},  // T=8
+    {3154, 4918, 6308, 7339, 6506, 6819, 7204, 8185, 7142, 6730, 7484, 8118, 7147, 7256, 7739, 8158},  // T=12
+    {3700, 5675, 6768, 8168, 6496, 5518, 7106, 8065, 5692, 6337, 6946, 7561, 6327, 6795, 7255, 7723},  // T=16
+    {3895, 5893, 6987, 8264, 5406, 6190, 7304, 8334, 5795, 6487, 7105, 7776, 6269, 7035, 7535, 8037},  // T=20
+    {4050, 6271, 7188, 8332, 5487, 6435, 7450, 8474, 5890, 6645, 7222, 7935, 6429, 7149, 7621, 8150},  // T=24
+    {4161, 6397, 7264, 8398, 6255, 6469, 7553, 8609, 6052, 6740, 7383, 8061, 6722, 7229, 7752, 8263},  // T=28
+    {4130, 6470, 6405, 8592, 4870, 5827, 6764, 7683, 6120, 6796, 7444, 8120, 0, 0, 0, 0},                 // T=32
+    {4144, 6660, 6398, 8523, 4902, 5900, 6674, 7809, 6154, 6874, 7083, 8217, 0, 0, 0, 0},                 // T=36
+};
+
+// Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the shape with the lowest
+// predicted time, passes x (padded cells of a pass / measured rate of that shape x makespan factor + launch cost).
+// With more than one pass the strip boundaries go through HBM and the first wave waits for its loads: not
+// measurable for W >= 8 (every query of 464 ... 5478 rows on a c5-shaped shard runs at 0.97 of its shape's rate,
+// like the one-pass ones), 17 % for the 4-wave shapes.
+// `room_for_lane_waves`: the database has a long-sequence tail that the lane kernel aligns on a second stream
+// while this kernel runs; only shapes that leave the 80 VGPRs per SIMD lane a lane-systolic wave needs are
+// admitted (e.g. 3 waves x 144, 4 x 104).
+// `overlapped`: the query runs beside two others (one-pass queries in rotation, see search_device), which cover the
+// workgroups that finish early: the makespan term is dropped.
+// `rg` / `rb`: plan for one range of a database that is streaming in (its columns, its own makespan factors) instead
+// of the whole resident database.
+int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bool overlapped, QueryPlan *out,
+                const Range *rg, BulkCols *rb)
+{
+    struct Cand { double base; double pass_base; int T, W, passes, n_wg; };
+    std::vector<Cand> cands;
+    const double cols = rg ? (double)rg->cols : (double)c->total_cols;
+    for (int ti = 7; ti >= 0; --ti) {
+        const int T = 8 + 4 * ti;
+        if (c->opt_T && T != c->opt_T) continue;
+        if (!pipe_has_variant(mode, T)) continue;
+        if (T == 28 && !c->opt_T && resident_for(c, 2)) continue;   // the group-resident 28-row kernel does not fit 128 VGPRs (16 spilled)
+        int maxW = (T > 28) ? 12 : 16;        // __launch_bounds__ of the instantiations
+        if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
+        const int strips = std::max(1, (m + T - 1) / T);
+        for (int W = 1; W <= maxW; ++W) {
+            if (c->opt_W > 0 && W != std::min(c->opt_W, maxW)) continue;
+            const int passes = (strips + W - 1) / W;
+            if (overlapped && passes != 1) continue;   // only one-pass queries take part in the rotation
+            int per_cu = 1;
+            if (wgs_per_cu(c, mode, T, W, resident_for(c, passes), &per_cu)) return 1;
+            if (room_for_lane_waves && !c->opt_T) {
+                int regs = 0;
+                if (kernel_regs(c, mode, T, resident_for(c, passes), &regs)) return 1;
+                const int alloc = (regs + 7) / 8 * 8;
+                if (alloc * ((per_cu * W + 3) / 4) > 512 - 80) continue;
+            }
+            // seconds: every pass aligns T x W rows against the whole resident database at the shape's rate, and costs
+            // a launch (pipeline fill and drain, staging, the last workgroups running alone: ~0.15 ms, which is what
+            // makes fewer, taller passes the better plan on a database of 1e8 residues)
+            const double pass_base = cols * kGroupSeqs * T * W / ((double)kShapeGcups[ti][W - 1] * 1e9);
+            cands.push_back(Cand{passes * (pass_base + 150e-6), pass_base, T, W, passes, n_workgroups(c, per_cu)});
+        }
+    }
+    // The makespan factor (>= 1) of a shape costs a simulated schedule per distinct workgroup count: cheapest shapes
+    // first, and stop at the first one that cannot win even with a perfectly even schedule.  (The order of equal
+    // costs is the order of the loops above: taller strips first.)
+    std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.base < b.base; });
+    double best_cost = -1;
+    for (const Cand &k : cands) {
+        if (best_cost >= 0 && k.base >= best_cost * (1.0 - 1e-9)) break;
+        const double imb = overlapped ? 1.0 : (rb ? lpt_imbalance(*rb, k.n_wg) : plan_imbalance(c, k.n_wg));
+        const double cost = k.passes * (k.pass_base * imb + 150e-6);
+        if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
+            best_cost = cost;
+            out->T = k.T; out->W = k.W; out->passes = k.passes; out->mpad = (uint32_t)(k.passes * k.W * k.T);
+        }
+    }
+    // (no admissible shape leaves a lane-systolic wave its registers, e.g. under a max_waves cap: the tail then shares)
+    if (best_cost < 0 && room_for_lane_waves) return choose_plan(c, mode, m, false, overlapped, out, rg, rb);
+    if (best_cost < 0) { fail("no kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W); return 1; }
+    return 0;
+}
+
+// upper bound of the profile elements of a query batch (25 codes x rows padded to at most 16 x 36 and to the lane kernel's 512)
+uint64_t prof_elems_bound(const uint16_t *qm, uint32_t qn)
+{
+    uint64_t n = 0;
+    for (uint32_t q = 0; q < qn; ++q) n += (uint64_t)kCodes * ((uint64_t)qm[q] + 16 * 36 + 64 * kLaneRows);
+    return n;
+}
+
+// The launch shapes of a group-resident batch (all queries of a shape run in one launch): the 4-wave shapes only --
+// measured (profiles/r02_ab_batch.txt), the group-resident kernel equals the per-pass kernel with 4-wave workgroups and
+// loses 9 % with 8.  First the shape that wastes the fewest padded rows over the whole batch at that shape's rate; a
+// query leaves it for a shape of its own only when that saves more than 12 % of its time (short queries: 96 instead of 128
+// rows), because every further shape is a further launch with an end of its own (60 queries of 1 200-1 400 residues:
+// 8 270 GCUPS in one launch, 8 010 in four).
+int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_t qn, std::vector<QueryPlan> &qps)
+{
+    double cost[8] = {};
+    int Wof[8] = {};
+    bool ok[8] = {};
+    auto rows_of = [](int m, int T, int W) { return (double)((m + T * W - 1) / (T * W)) * T * W; };
+    for (int ti = 7; ti >= 0; --ti) {
+        const int T = 8 + 4 * ti;
+        if (c->opt_T && T != c->opt_T) continue;
+        if (!pipe_has_variant(mode, T)) continue;
+        if (T == 28 && !c->opt_T) continue;                       // the group-resident 28-row kernel does not fit 128 VGPRs
+        Wof[ti] = c->opt_W > 0 ? std::min(c->opt_W, T > 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
+        ok[ti] = true;
+        for (uint32_t q = 0; q < qn; ++q) cost[ti] += rows_of(qm[q], T, Wof[ti]) / kShapeGcups[ti][Wof[ti] - 1];
+    }
+    int common = -1;
+    for (int ti = 7; ti >= 0; --ti)
+        if (ok[ti] && (common < 0 || cost[ti] < cost[common])) common = ti;
+    if (common < 0) return fail("no group-resident kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W);
+    for (uint32_t q = 0; q < qn; ++q) {
+        int pick = common;
+        const double cc = rows_of(qm[q], 8 + 4 * common, Wof[common]) / kShapeGcups[common][Wof[common] - 1];
+        double bc = cc;
+        for (int ti = 7; ti >= 0; --ti) {
+            if (!ok[ti]) continue;
+            const double x = rows_of(qm[q], 8 + 4 * ti, Wof[ti]) / kShapeGcups[ti][Wof[ti] - 1];
+            if (x < 0.88 * cc && x < bc) { bc = x; pick = ti; }
+        }
+        QueryPlan &qp = qps[q];
+        qp.T = 8 + 4 * pick; qp.W = Wof[pick];
+        const int strips = std::max(1, (qm[q] + qp.T - 1) / qp.T);
+        qp.passes = (strips + qp.W - 1) / qp.W;
+        qp.mpad = (uint32_t)(qp.passes * qp.W * qp.T);
+    }
+    return 0;
+}
+
+
+// LPT: longest unit first onto the least-loaded workgroup; cost = columns (exact, every column of a
+// unit costs the same T*W*128 cells)
+int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, Plan &pl)
+{
+    n_wg = std::max(1, std::min<int>(n_wg, (int)units.size()));
+    std::vector<uint32_t> order(units.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return units[a].ncols > units[b].ncols; });
+    typedef std::pair<uint64_t, int> Load;
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int w = 0; w < n_wg; ++w) heap.push(Load(0, w));
+    std::vector<std::vector<uint32_t>> bins(n_wg);
+    std::vector<uint64_t> load(n_wg, 0);
+    for (uint32_t idx : order) {
+        Load l = heap.top(); heap.pop();
+        bins[l.second].push_back(idx);
+        load[l.second] = l.first + units[idx].ncols;
+        heap.push(Load(load[l.second], l.second));
+    }
+    std::vector<Item> items; items.reserve(units.size());
+    std::vector<uint32_t> first(n_wg + 1, 0), chunks(n_wg, 0);
+    pl.max_wg_chunks = 0; pl.total_chunks = 0;
+    for (int w = 0; w < n_wg; ++w) {
+        first[w] = (uint32_t)items.size();
+        for (uint32_t idx : bins[w]) {
+            const WorkUnit &u = units[idx];
+            const GroupDesc &gd = c->groups[u.group];
+            Item it{}; it.db = gd.db; it.ncols = gd.ncols; it.seq0 = gd.seq0; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = u.bnd_off;
+            items.push_back(it);
+        }
+        chunks[w] = (uint32_t)(load[w] / kChunkCols);
+        pl.max_wg_chunks = std::max<uint64_t>(pl.max_wg_chunks, chunks[w]);
+        pl.total_chunks += chunks[w];
+    }
+    first[n_wg] = (uint32_t)items.size();
+    pl.n_wg = n_wg;
+    std::vector<Item> sorted; sorted.reserve(units.size());
+    pl.queue_cols.clear();
+    uint64_t before = 0;
+    for (uint32_t idx : order) {
+        const WorkUnit &u = units[idx];
+        const GroupDesc &gd = c->groups[u.group];
+        Item it{}; it.db = gd.db; it.ncols = gd.ncols; it.seq0 = gd.seq0; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = before;
+        before += u.ncols;
+        sorted.push_back(it);
+        pl.queue_cols.push_back(u.ncols);
+    }
+    pl.n_items = (uint32_t)sorted.size();
+    {   // the same list as two interleaved halves, each sorted longest first, boundary offsets counted along this order
+        std::vector<Item> split; split.reserve(sorted.size());
+        uint64_t off = 0;
+        for (int h = 0; h < 2; ++h) {
+            pl.split_n[h] = 0; pl.split_cols[h] = 0;
+            for (size_t i = (size_t)h; i < sorted.size(); i += 2) {
+                Item it = sorted[i];
+                it.bnd_off = off;
+                off += pl.queue_cols[i];
+                pl.split_cols[h] += pl.queue_cols[i];
+                pl.split_n[h]++;
+                split.push_back(it);
+            }
+        }
+        HIP_TRY(pl.split_items.reserve(split.size()));
+        if (list_copy(c, pl.split_items.p, split.data(), split.size() * sizeof(Item))) return 1;
+    }
+    HIP_TRY(pl.queue_items.reserve(sorted.size()));
+    if (list_copy(c, pl.queue_items.p, sorted.data(), sorted.size() * sizeof(Item))) return 1;
+    HIP_TRY(pl.items.reserve(items.size()));
+    HIP_TRY(pl.wg_first.reserve(first.size()));
+    HIP_TRY(pl.wg_chunks.reserve(chunks.size()));
+    if (list_copy(c, pl.items.p, items.data(), items.size() * sizeof(Item)) ||
+        list_copy(c, pl.wg_first.p, first.data(), first.size() * sizeof(uint32_t)) ||
+        list_copy(c, pl.wg_chunks.p, chunks.data(), chunks.size() * sizeof(uint32_t)) || list_sync(c)) return 1;
+    return 0;
+}
+
+int upload_lane_items(swimm_hip_ctx *c, std::vector<LaneItem> &v, LaneList &ll)
+{
+    std::stable_sort(v.begin(), v.end(), [](const LaneItem &a, const LaneItem &b) { return a.ncols > b.ncols; });
+    uint64_t cols = 0;
+    for (LaneItem &it : v) {
+        if (cols + it.ncols > 0xFFFFFFFFull) return fail("lane work list exceeds 2^32 boundary columns");
+        it.bnd_off = (uint32_t)cols;
+        cols += it.ncols;
+    }
+    ll.n = (uint32_t)v.size();
+    ll.cols = cols;
+    ll.cell_cols = cols;
+    HIP_TRY(ll.items.reserve(v.size()));
+    if (list_copy(c, ll.items.p, v.data(), v.size() * sizeof(LaneItem)) || list_sync(c)) return 1;
+    return 0;
+}
+
+// Which groups leave the workgroup pipeline for the lane-systolic kernel: a group is one serial chain on
+// one workgroup, so any group longer than a fraction of the mean per-workgroup load would set the
+// kernel's makespan (Swiss-Prot's 35 000-residue titin against a 360-residue mean).  Longest first, move
+// groups while ncols > tail_alpha * (remaining columns / n_wg).
+std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> flag per group of the range
+{
+    const uint32_t n = rg.g1 - rg.g0;
+    // (a database that is streaming in: "long" is judged against the whole database, not against the range that
+    // happens to hold the group -- a range of nothing but the longest sequences is bulk work like any other)
+    if (c->streaming_now && c->stream_tail.size() == c->groups.size() && n != c->groups.size())
+        return std::vector<uint8_t>(c->stream_tail.begin() + rg.g0, c->stream_tail.begin() + rg.g1);
+    std::vector<uint8_t> is_tail(n, 0);
+    if (c->opt_tail_mode == 2) return is_tail;                        // never
+    if (c->opt_tail_mode == 1) { std::fill(is_tail.begin(), is_tail.end(), 1); return is_tail; }   // always
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->groups[rg.g0 + a].ncols > c->groups[rg.g0 + b].ncols; });
+    uint64_t rest = rg.cols;
+    // the yardstick is the load of a CU, however many workgroups share it
+    for (uint32_t g : order) {
+        const double mean = (double)rest / c->num_cu;
+        if ((double)c->groups[rg.g0 + g].ncols <= c->opt_tail_frac * 0.01 * mean) break;
+        is_tail[g] = 1;
+        rest -= c->groups[rg.g0 + g].ncols;
+    }
+    return is_tail;
+}
+
+// work lists of one range for launches of n_wg workgroups: the pipeline kernel's items and the lane-systolic tail
+int make_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool no_tail, const Range &rg, bool exact_lengths, DbPlan &dp)
+{
+    std::vector<WorkUnit> units;
+    std::vector<LaneItem> tail;
+    uint64_t bnd_cols = 0;
+    const uint64_t col0 = rg.g0 < c->group_col_off.size() ? c->group_col_off[rg.g0] : 0;
+    if (mode != Mode::I32) {
+        std::vector<uint8_t> is_tail = pick_tail(c, rg);
+        if (no_tail) std::fill(is_tail.begin(), is_tail.end(), 0);   // every group through the pipeline kernel
+        for (uint32_t g = rg.g0; g < rg.g1; ++g) {
+            const GroupDesc &gd = c->groups[g];
+            if (!is_tail[g - rg.g0]) { units.push_back(WorkUnit{g, 0, 0, gd.ncols, c->group_col_off[g] - col0}); continue; }
+            for (uint32_t l = 0; l < 64; ++l) {
+                // a pair only runs to the end of its longer member, not to the end of the group (when the lengths are
+                // already known: a chunk that is still streaming in runs to the end of its group -- padding scores 0)
+                const uint32_t len = exact_lengths ? std::max(c->seq_len[gd.seq0 + l], c->seq_len[gd.seq0 + 64 + l]) : gd.ncols;
+                if (len == 0) continue;                 // empty pair: scores stay 0
+                LaneItem li{};
+                li.db = gd.db; li.lane = l; li.half = 0; li.ncols = (len + kChunkCols - 1) / kChunkCols * kChunkCols;
+                li.slot_a = gd.seq0 + l; li.slot_b = gd.seq0 + 64 + l;
+                tail.push_back(li);
+            }
+        }
+        bnd_cols = rg.cols;
+    } else {
+        for (uint32_t g = rg.g0; g < rg.g1; ++g)
+            for (uint32_t h = 0; h < 2; ++h)
+                units.push_back(WorkUnit{g, h, c->groups[g].seq0 / 64 + h, c->groups[g].ncols,
+                                         2 * (c->group_col_off[g] - col0) + (uint64_t)h * c->groups[g].ncols});
+        bnd_cols = 2 * rg.cols;
+    }
+    if (!units.empty()) {
+        if (build_plan(c, units, n_wg, dp.main)) return 1;
+        dp.main.bnd_cols = bnd_cols;
+        dp.have_main = true;
+    }
+    if (!tail.empty() && upload_lane_items(c, tail, dp.tail)) return 1;
+    return 0;
+}
+
+// the resident database's work lists, cached per launch shape
+int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool whole_db, DbPlan **out)
+{
+    const int key = n_wg | (mode == Mode::I32 ? (1 << 30) : 0) | (whole_db ? (1 << 29) : 0);   // packed int16 and f16 share plans
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) { *out = &it->second; return 0; }
+    DbPlan &dp = c->plans[key];
+    if (make_db_plan(c, mode, n_wg, whole_db, whole_range(c), true, dp)) return 1;
+    *out = &dp;
+    return 0;
+}
+
+void fill_common(const swimm_hip_ctx *c, const QueryPlan &qp, PipeParams &p, uint2 *bnd)
+{
+    p.prof = c->d_prof.p + qp.prof_off;
+    p.prof_stride = qp.mpad;
+    p.bnd = bnd;
+    p.goe = c->open_gap + c->extend_gap;
+    p.ge = c->extend_gap;
+}
+
+// columns of boundary rows (64 lanes x 8 B each) the pass-boundary buffer may hold
+uint64_t bnd_budget_cols(const swimm_hip_ctx *c) { return ((uint64_t)c->opt_bnd_mib << 20) / (64 * sizeof(uint2)); }
+
+// Cuts the longest-first item list into runs whose boundary rows fit the budget (always at least one item).  A
+// multi-pass query takes every run through all its passes before the next run starts, so the buffer holds one
+// run's columns only: 4x the run's tiled residue bytes instead of 4x the whole database.
+void boundary_segments(const swimm_hip_ctx *c, const Plan &pl, std::vector<std::pair<uint32_t, uint32_t>> &segs, uint64_t *max_cols)
+{
+    const uint64_t budget = bnd_budget_cols(c);
+    segs.clear();
+    uint64_t mx = 0, cur = 0;
+    uint32_t first = 0;
+    for (uint32_t i = 0; i < pl.n_items; ++i) {
+        if (i > first && cur + pl.queue_cols[i] > budget) { segs.push_back({first, i}); mx = std::max(mx, cur); first = i; cur = 0; }
+        cur += pl.queue_cols[i];
+    }
+    if (pl.n_items > first) { segs.push_back({first, pl.n_items}); mx = std::max(mx, cur); }
+    if (max_cols) *max_cols = mx;
+}
+
+// Multi-pass query, whole list in one boundary run: the even- and the odd-ranked groups go through their passes as two
+// kernels on two streams.  A pass of one half cannot start before the previous pass of the same half has ended, but
+// it can start while the other half is in full swing, so the end of every launch -- the last workgroups finishing
+// alone, 4 % of a 4 ms pass on a 2e8-residue database -- and the start of the next are covered by the other kernel.
+bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &pl, size_t n_segs)
+{
+    // (two passes gain nothing: measured -0.3 % on c2; neither do long passes, whose end is a small part of them: c2 with
+    // 3 passes of 9 ms each 27.15 ms split, 26.97 ms not -- the split is for passes of up to ~5 ms at 8 000 GCUPS)
+    const double pass_cells = (double)pl.total_chunks * kChunkCols * kGroupSeqs * qp.T * qp.W;
+    return c->opt_dynamic && c->opt_split && qp.passes > 2 && n_segs == 1 && pl.n_wg >= 2 && pl.split_n[1] >= (uint32_t)pl.n_wg && pass_cells < 4e10;
+}
+
+
+}  // namespace swimm_impl

@@ -1,4 +1,4 @@
-// Internal interface between the C-ABI shim (swimm_hip.cpp) and the device code
+// Internal interface between the library's host side (swimm_hip.cpp, search.cpp, plan.cpp, upload.cpp) and the device code
 // (sw_kernels.hip).  Not installed; the public boundary is include/swimm_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,0 +1,357 @@
+// swimm_impl.h -- what the translation units of libswimm_hip.so share: the context behind the C-ABI handle, the
+// work-list and upload records, and the functions of plan.cpp (launch plans and work lists), upload.cpp (chunks,
+// the uploader thread) and search.cpp (one search) that the others call.  Not installed: include/swimm_hip.h is the boundary.
+#pragma once
+#include "../../include/swimm_hip.h"
+#include "sw_kernels.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <cxxabi.h>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace swimm;
+
+namespace swimm_impl {
+
+
+extern thread_local std::string g_err;     // the calling thread's last error (swimm_hip_last_error)
+
+inline int fail(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) return fail("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+inline double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T>
+struct DevBuf {   // grow-only device scratch
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// the lengths of a run of bulk groups, longest first, with the makespan factors already worked out for it
+struct BulkCols {
+    std::vector<uint32_t> cols;
+    uint64_t total = 0;
+    std::map<int, double> cache;    // n_wg -> LPT makespan / mean load
+};
+
+struct Plan {      // static partition of a work list over n_wg persistent workgroups
+    int n_wg = 0;
+    DevBuf<Item> items;          // grouped by workgroup (static partition)
+    DevBuf<uint32_t> wg_first, wg_chunks;
+    DevBuf<Item> queue_items;    // the same items sorted longest first (dynamic queue); bnd_off = columns before the item in this order
+    std::vector<uint32_t> queue_cols;   // their column counts (host copy, for cutting the list into boundary-buffer segments)
+    DevBuf<Item> split_items;    // the even-ranked items of that list followed by the odd-ranked ones (two-stream launches)
+    uint32_t split_n[2] = {0, 0};
+    uint64_t split_cols[2] = {0, 0};
+    uint32_t n_items = 0;
+    uint64_t bnd_cols = 0;   // columns the pass-boundary buffer must hold
+    uint64_t max_wg_chunks = 0, total_chunks = 0;
+    void release() { items.release(); wg_first.release(); wg_chunks.release(); queue_items.release(); split_items.release(); }
+};
+
+// lane-systolic work list (long-sequence tail, int32 promotion): items sorted longest first, pulled
+// dynamically by the waves
+struct LaneList {
+    DevBuf<LaneItem> items;
+    uint32_t n = 0;
+    uint64_t cols = 0;       // boundary columns (sum of ncols)
+    uint64_t cell_cols = 0;  // sum of ncols (for the cell statistics)
+    void release() { items.release(); n = 0; }
+};
+
+struct DbPlan {          // per (mode, n_wg): main partition + the groups handed to the lane kernel
+    Plan main;
+    bool have_main = false;
+    LaneList tail;
+};
+
+// scratch of one lane-kernel stream: boundary rows of even / odd passes, per-pass queues, progress counters
+struct LaneScratch {
+    DevBuf<unsigned long long> bnd[2];
+    DevBuf<uint32_t> queue, prog;
+    void release() { bnd[0].release(); bnd[1].release(); queue.release(); prog.release(); }
+};
+
+struct Uploader;      // the thread that copies a lazily uploaded database (below, with upload_chunk)
+
+struct ChunkRec {
+    uint8_t *d_tiled = nullptr;
+    uint32_t *d_len = nullptr;  // chunk-layout chunks: every slot's true length, written by the re-tile kernel
+    uint64_t first_seq = 0;     // global sorted index of the chunk's first sequence
+    uint64_t n_seq = 0;         // group_count * vl
+    uint32_t group0 = 0, n_groups = 0;
+    uint64_t cols = 0;          // padded columns of the chunk's device groups
+    // upload source: the caller's buffers.  Eager mode (default) copies inside add_chunk / add_sequences; with the
+    // option "lazy_upload" they are only recorded and the first search streams them in (X2 overlapped with compute,
+    // MICsearch.c:85-91), so they must stay valid until that search has returned.
+    int kind = 0;               // 0 = reference chunk layout (re-tile), 1 = .seq slab (tile)
+    const char *h_b = nullptr; uint64_t vD = 0; const uint16_t *h_n = nullptr; const uint32_t *h_disp = nullptr;
+    uint32_t group_count = 0, vl = 0;
+    const char *h_codes = nullptr; uint64_t code_bytes = 0;
+    std::vector<uint32_t> off;  // kind 1: residue offset of every sequence (n_seq + 1)
+    std::vector<uint64_t> goff; // byte offset of every device group in d_tiled
+    std::vector<uint32_t> gcols;
+    bool uploaded = false, lens_known = false;
+    hipEvent_t ready = nullptr; // recorded on the upload stream behind the chunk's (re-)tile kernel
+};
+
+struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true, resident = false; };
+
+
+struct Range { uint32_t g0 = 0, g1 = 0; uint64_t cols = 0; };
+struct WorkUnit { uint32_t group, half, out_slot; uint32_t ncols; uint64_t bnd_off; };
+
+}  // namespace swimm_impl
+
+using namespace swimm_impl;
+
+struct swimm_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t stream_b = nullptr;     // second bulk stream: multi-pass queries run the two halves of the group list side by side
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipStream_t stream2 = nullptr;      // lane-systolic tail runs beside the bulk kernel
+    hipEvent_t ev_tail = nullptr;
+    hipStream_t stream_up = nullptr;    // uploads: H2D copies, (re-)tile kernels, work lists -- never waits for a DP kernel
+    hipEvent_t ev_copied = nullptr;
+    DevBuf<uint8_t> up_b; DevBuf<uint16_t> up_n; DevBuf<uint32_t> up_disp, up_gcols, up_off; DevBuf<uint64_t> up_goff;   // upload scratch, reused chunk after chunk
+    int opt_lazy_upload = 0;            // 1: add_chunk / add_sequences record the caller's buffers, the first search streams them in
+    hipStream_t stream3 = nullptr;      // promotion re-runs
+    hipEvent_t ev_ready = nullptr, ev_tail3 = nullptr;
+    std::vector<hipEvent_t> ev_query;   // [2q] bulk done, [2q+1] tail done
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cu = 0;
+    // options (swimm_hip_set_option)
+    int opt_T = 0, opt_maxW = 0, opt_W = 0, opt_wgs_per_cu = 0;   // launch shape: 0 = chosen per query
+    int opt_force_i32 = 0;              // 1: everything in int32
+    int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
+    int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
+    int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
+    int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
+    int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
+    int opt_resident = -1;              // group-resident batch launches: -1 = when the batch has two or more queries that are not rotated, 0 never, 1 always
+    int opt_lane_room = -1;             // launch shapes must leave a lane-systolic wave its registers: -1 = when the database has a long-sequence tail, 0 never, 1 always
+    bool batch_now = false;             // the search in progress runs its non-rotated queries as group-resident batch launches
+    std::vector<uint8_t> stream_tail;   // streaming search: the tail flags of the whole database (pick_tail)
+    bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
+    DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
+    int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
+    std::vector<hipEvent_t> launch_ev;  // pairs (before, after), grown on demand
+    size_t launch_ev_used = 0;
+    double launch_ms_sum = 0;           // sum of the pipeline launches' own durations in the last search
+    uint32_t launch_ms_n = 0;
+    int opt_rotate = 1;                 // 1: eight or more one-pass queries run whole on three streams in rotation; 0: they join the group-resident batch
+    int opt_alternate = 1;              // 1: the passes of consecutive multi-pass queries alternate between two streams
+    int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
+    int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
+    int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
+    int opt_lane_acquire = 0;           // 1: chained lane passes take an agent-scope acquire after every progress poll (default: sc1 loads only)
+    int opt_wg_limit = 0;               // > 0: at most this many persistent workgroups per pipeline launch (tests: long per-workgroup item sequences on a small database)
+    // caches that depend on the resident database / the code objects
+    BulkCols bulk;                      // the resident database's bulk groups (built on demand) and their makespan factors
+    int regs_cache[2][3][40] = {};      // VGPRs of sw_pipe_kernel<T, tier, dynamic, group-resident or not>, looked up once
+    DevBuf<uint32_t> d_queue;           // one cursor per pipeline launch of a search
+    uint32_t queue_next = 0;
+    // queries (host copies; profiles are built per search because T/W may change)
+    std::vector<int8_t> qcodes;
+    std::vector<uint16_t> qm;
+    std::vector<uint32_t> qdisp;
+    int8_t submat[SWIMM_HIP_SUBMAT_BYTES];
+    int open_gap = 10, extend_gap = 2, max_pos = 0;
+    bool have_queries = false;
+    // database
+    std::vector<ChunkRec> chunks;
+    std::vector<GroupDesc> groups;
+    std::vector<uint64_t> group_col_off;
+    std::vector<uint32_t> seq_len;      // true length of every local slot (from the re-tile kernel)
+    uint64_t total_cols = 0;
+    bool groups_dirty = true;
+    std::map<int, DbPlan> plans;        // key: n_wg (packed mode), n_wg | 1<<30 (whole-db int32 mode)
+    // scratch
+    DevBuf<int32_t> d_scores;
+    DevBuf<int16_t> d_prof;
+    DevBuf<uint2> d_bnd, d_bnd_b;       // pass-boundary rows; the second one for the queries whose passes run on stream_b
+    DevBuf<uint2> d_bnd_c;              // ... and a third for the group-resident launches of a database that streams in (three ranges in flight)
+    Uploader *up = nullptr;             // the thread that copies a lazily uploaded database (created with the first recorded chunk)
+    void *pin = nullptr;                // pinned arena the work lists travel through (list_copy)
+    size_t pin_cap = 0, pin_used = 0;
+    DevBuf<int64_t> d_gbase;
+    DevBuf<uint32_t> d_gvalid;
+    DevBuf<unsigned long long> d_keys;
+    DevBuf<uint32_t> d_err;             // pipeline watchdog word
+    DevBuf<unsigned long long> d_stamps;   // diagnostic build only
+    LaneScratch tail_scratch;           // lane kernel on stream 2 (long-sequence tail)
+    LaneScratch tail_scratch_a, tail_scratch_b;   // one-pass queries that run whole on the main stream / on stream_b
+    // a search whose time is set by the long-sequence chains (a small database with one extreme sequence, many queries)
+    // runs up to three queries' tail launches side by side: two more streams (created on first use), scratch and events
+    hipStream_t stream_t[2] = {nullptr, nullptr};
+    hipEvent_t ev_tail_t[2] = {nullptr, nullptr};
+    LaneScratch tail_scratch_t[2];
+    LaneScratch rerun_scratch;          // lane kernel on stream 3 (promotion re-runs)
+    DevBuf<LaneItem> d_rerun_items;
+    DevBuf<uint32_t> d_satlist;
+    // stats of the last search
+    double kernel_ms = 0;
+    uint64_t cells = 0, promoted = 0, promoted16 = 0;
+    std::vector<QueryPlan> last_plans;
+    uint32_t launches = 0;
+};
+
+namespace swimm_impl {
+
+int upload_chunk(swimm_hip_ctx *c, ChunkRec &r);
+
+// The uploader of a database that streams in (option "lazy_upload"): a thread of its own, one per context, started when
+// the first chunk is recorded and parked between searches.  The copies come from pageable memory, so each one blocks its
+// caller for the length of the transfer: on this thread the link is busy back to back (0.6 GB in 13-15 ms) while the
+// searching thread plans, builds work lists and launches, and since the link delivers 1.8x faster than the kernels
+// consume, the GPU waits for the first range only.  (A thread per search would do, but its first HIP call costs
+// up to 5 ms on some runs.)
+struct Uploader {
+    swimm_hip_ctx *c;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<size_t> order;      // the job: chunk indices in the order they travel
+    bool have_job = false, busy = false, quit = false, stop = false;
+    size_t issued = 0;              // the first `issued` chunks of `order` have their `ready` event recorded
+    bool failed = false;
+    std::string err;
+
+    explicit Uploader(swimm_hip_ctx *ctx) : c(ctx) { th = std::thread([this]() { run(); }); }
+    ~Uploader()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    void run()
+    {
+        bool dev_ok = hipSetDevice(c->device) == hipSuccess;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&]() { return have_job || quit; });
+            if (quit) return;
+            have_job = false;
+            const std::vector<size_t> job = order;
+            lk.unlock();
+            bool ok = dev_ok;
+            std::string e = ok ? "" : "uploader: hipSetDevice failed";
+            for (size_t i = 0; i < job.size(); ++i) {
+                bool skip;
+                { std::lock_guard<std::mutex> g(mu); skip = stop; }
+                if (ok && !skip && upload_chunk(c, c->chunks[job[i]])) { ok = false; e = g_err; }
+                std::lock_guard<std::mutex> g(mu);
+                issued = i + 1; failed = !ok; err = e;
+                cv.notify_all();
+            }
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void post(const std::vector<size_t> &job)
+    {
+        { std::lock_guard<std::mutex> lk(mu); order = job; issued = 0; failed = false; err.clear(); stop = false; have_job = true; busy = true; }
+        cv.notify_all();
+    }
+    int wait_issued(size_t n, std::string *e)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return issued >= n || failed || !busy; });
+        if (failed) { *e = err; return 1; }
+        return issued >= n ? 0 : 1;
+    }
+    void finish(bool abandon)       // the job has been walked to its end (abandon: without copying what is left)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (abandon) stop = true;
+        cv.wait(lk, [&]() { return !busy; });
+    }
+};
+
+// ---- plan.cpp: occupancy, launch plans, work lists
+void release_plans(swimm_hip_ctx *c);
+int regs_to_waves_per_simd(int regs);
+int kernel_regs(const swimm_hip_ctx *c, Mode mode, int T, bool resident, int *out);
+int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, bool resident, int *out);
+bool resident_for(const swimm_hip_ctx *c, int passes);
+int n_workgroups(const swimm_hip_ctx *c, int per_cu);      // persistent workgroups of a pipeline launch: what the chip holds, unless the caller caps it
+hipStream_t list_stream(const swimm_hip_ctx *c);
+int list_copy(swimm_hip_ctx *c, void *dst, const void *src, size_t bytes);
+int list_sync(swimm_hip_ctx *c);
+Range whole_range(const swimm_hip_ctx *c);
+std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg);
+double lpt_imbalance(BulkCols &b, int n_wg);
+void bulk_cols_of(const swimm_hip_ctx *c, const Range &rg, BulkCols &b);
+double plan_imbalance(swimm_hip_ctx *c, int n_wg);
+int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bool overlapped, QueryPlan *out,
+                const Range *rg = nullptr, BulkCols *rb = nullptr);
+uint64_t prof_elems_bound(const uint16_t *qm, uint32_t qn);
+int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_t qn, std::vector<QueryPlan> &qps);
+int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, Plan &pl);
+int upload_lane_items(swimm_hip_ctx *c, std::vector<LaneItem> &v, LaneList &ll);
+int make_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool no_tail, const Range &rg, bool exact_lengths, DbPlan &dp);
+int get_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool whole_db, DbPlan **out);
+void fill_common(const swimm_hip_ctx *c, const QueryPlan &qp, PipeParams &p, uint2 *bnd);
+uint64_t bnd_budget_cols(const swimm_hip_ctx *c);
+void boundary_segments(const swimm_hip_ctx *c, const Plan &pl, std::vector<std::pair<uint32_t, uint32_t>> &segs, uint64_t *max_cols);
+bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &pl, size_t n_segs);
+
+// ---- upload.cpp: chunks (upload_chunk is declared above, before the Uploader)
+int refresh_plans(swimm_hip_ctx *c);
+int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> &lens_or_empty);
+int ensure_uploader(swimm_hip_ctx *c);
+int sync_lengths(swimm_hip_ctx *c);
+
+// ---- search.cpp: the launches of one search
+int timed_launch(swimm_hip_ctx *c, Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t st);
+uint64_t resident_bnd_elems(const Plan &pl);
+int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl, const QDesc *qd, uint32_t nq, uint64_t pass_sum, uint32_t max_passes,
+                       hipStream_t st, DevBuf<uint2> &bnd);
+int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st, bool allow_split, DevBuf<uint2> &bnd);
+int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row, hipStream_t st,
+                    LaneScratch &sc);
+int reserve_lane_scratch(LaneScratch &sc, size_t cols, size_t items, int passes);
+int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_out);
+
+}  // namespace swimm_impl

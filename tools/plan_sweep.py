@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measures the pipeline kernel's throughput for every (rows per wave T, waves per workgroup W) launch shape on
 one c2-shaped shard: query length m = T*W (one pass, no padding rows), so the figure is the shape's own
-efficiency.  The launch-plan model in swimm_hip.cpp (choose_plan) is calibrated against this table.
+efficiency.  The launch-plan model in plan.cpp (choose_plan) is calibrated against this table.
 
     python tools/plan_sweep.py [--scale 0.3] [--ts 8,12,...] [--ws 4,8,12,16]
 """

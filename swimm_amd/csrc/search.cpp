@@ -563,8 +563,12 @@ int SearchRun::size_buffers()
                     if (wgs_per_cu(c, main_mode, qp.T, qp.W, c->batch_now && !rotated[q], &per_cu)) return 1;
                     const uint64_t cols = ranges[ri].cols * (main_mode == Mode::I32 ? 2 : 1);
                     if (qps[q].resident) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_all * 64);   // (a batch takes every group)
-                    else need_bnd = std::max<uint64_t>(need_bnd, std::min<uint64_t>(cols, std::max<uint64_t>(budget, longest_main)) * 64);
-                    launch_total += (size_t)qp.passes * (size_t)(cols / std::max<uint64_t>(budget, 1) + 2);
+                    // (only the dynamic queue's list is cut into runs that fit the budget: the static partition takes the range whole)
+                    else need_bnd = std::max<uint64_t>(need_bnd, (c->opt_dynamic ? std::min<uint64_t>(cols, std::max<uint64_t>(budget, longest_main)) : cols) * 64);
+                    // (runs of the boundary buffer: the greedy cut closes a run when the next item would overflow it, so two
+                    // consecutive runs together exceed the budget -- at most 2 cols / budget + 1 of them, and never more than items)
+                    const uint64_t items = (uint64_t)(ranges[ri].g1 - ranges[ri].g0) * (main_mode == Mode::I32 ? 2 : 1);
+                    launch_total += (size_t)qp.passes * (size_t)(std::min<uint64_t>(items, 2 * cols / std::max<uint64_t>(budget, 1) + 1) + 2);
                 }
             }
         } else

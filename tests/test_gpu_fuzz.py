@@ -1,0 +1,89 @@
+"""Randomised parity: databases, query batches, penalties, upload paths and library options drawn from a seed, the whole
+score matrix against the CPU checker (the reference's AVX2 path when oracle/_ref is built).  Every seed is a fixed
+case; a failure names the seed and the options.  SWIMM_FUZZ_FIRST / SWIMM_FUZZ_SEEDS widen the sweep (default: seeds 0..159)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import oracle_matrix
+from swimm_amd import hip_backend, host, submat
+
+pytestmark = pytest.mark.gpu
+
+MATRICES = ["blosum45", "blosum50", "blosum62", "blosum80", "blosum90", "pam30", "pam70", "pam250"]
+
+
+def draw_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 100, 129, 1500, 6000, 20000, 20000, 70000]))
+    mean = float(rng.choice([30, 120, 350]))
+    L = np.clip(rng.lognormal(np.log(mean), 0.6, n), 1, 3000).astype(np.int64)
+    for _ in range(int(rng.integers(0, 4))):                      # a few long sequences: the lane-systolic tail
+        L[rng.integers(0, n)] = int(rng.integers(2000, 9000))
+    if rng.random() < 0.3:
+        L[rng.integers(0, n)] = 0                                  # an empty record
+    L = np.sort(L).astype(np.uint16)
+    total = int(L.astype(np.int64).sum())
+    codes = rng.integers(0, 23, total).astype(np.int8)
+    offs = np.concatenate([[0], np.cumsum(L.astype(np.int64))])
+    nq = int(rng.choice([1, 2, 3, 5, 9, 14]))
+    qlens = np.sort(np.clip(rng.lognormal(np.log(float(rng.choice([20, 150, 700]))), 0.8, nq), 1, 2600).astype(np.int64))
+    queries = []
+    for ql in qlens:
+        q = rng.integers(0, 23, int(ql)).astype(np.int8)
+        if total and rng.random() < 0.6:                           # plant a piece of a database sequence: real alignments
+            i = int(rng.integers(0, n))
+            if L[i] > 4:
+                k = int(min(L[i], ql, rng.integers(4, 400)))
+                q[:k] = codes[offs[i]:offs[i] + k]
+        queries.append(q)
+    m = np.array([len(q) for q in queries], np.uint16)
+    disp = np.concatenate([[0], np.cumsum(m.astype(np.int64))]).astype(np.uint32)
+    w = {"lengths": L, "codes": codes, "offs": offs, "n": n, "residues": total, "a": np.concatenate(queries), "m": m, "disp": disp,
+         "query_residues": int(m.astype(np.int64).sum()), "matrix": str(rng.choice(MATRICES))}
+    go, ge = int(rng.integers(0, 21)), int(rng.integers(0, 6))
+    opts = {}
+    pool = [("resident", [0, 1]), ("dynamic", [0]), ("tail_mode", [1, 2]), ("f16", [0]), ("force_i32", [1]), ("wg_limit", [4, 64]),
+            ("bnd_mib", [1]), ("alternate", [0]), ("split", [0]), ("rotate", [0]), ("lane_rows", [0]), ("score_mib", [1]), ("tail_frac", [10, 200]),
+            ("lane_room", [0, 1]), ("lane_acquire", [1]), ("max_waves", [1, 4, 8])]
+    for key, vals in pool:
+        if rng.random() < 0.2:
+            opts[key] = int(rng.choice(vals))
+    if rng.random() < 0.35 and "force_i32" not in opts and "f16" not in opts:
+        T = int(rng.choice([8, 12, 16, 20, 24, 28, 32, 36]))
+        opts["rows_per_wave"] = T
+        opts["waves"] = int(rng.integers(1, (12 if T > 28 else 16) + 1))
+    path = str(rng.choice(["chunks", "chunks_lazy", "slabs", "slabs_lazy"]))
+    return w, go, ge, opts, path, rng
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWIMM_FUZZ_FIRST", "0")), int(os.environ.get("SWIMM_FUZZ_FIRST", "0")) + int(os.environ.get("SWIMM_FUZZ_SEEDS", "160"))))
+def test_random_case_against_the_checker(seed):
+    w, go, ge, opts, path, rng = draw_case(seed)
+    sm = submat.table(w["matrix"])
+    chunks = None
+    with hip_backend.HipSearcher(0) as s:
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.set_option("lazy_upload", 1 if path.endswith("lazy") else 0)
+        s.set_queries(w["a"], w["m"], w["disp"], sm, go, ge)
+        if path.startswith("chunks"):
+            chunks = host.Chunks(w["lengths"], w["codes"], 128, int(rng.choice([2000, 50000, 1 << 20, 96 << 20])))
+            for c in chunks.chunks:
+                s.add_chunk(c["b"], c["n"], c["disp"], 128, c["first_group"])
+            stride = chunks.vc * 128
+        else:
+            cuts = sorted(set([0, w["n"]] + [int(x) // 128 * 128 for x in rng.integers(0, w["n"] + 1, int(rng.integers(0, 6)))]))
+            for s0, s1 in zip(cuts[:-1], cuts[1:]):
+                s.add_sequences(w["lengths"][s0:s1], w["codes"][w["offs"][s0]:w["offs"][s1]], first_seq=s0)
+            stride = (w["n"] + 127) // 128 * 128
+        got, _ = s.search(stride)
+        again, _ = s.search(stride)                    # the resident copy (after a streamed first search)
+    if chunks is not None:
+        chunks.close()
+    want, idx = oracle_matrix(w, go=go, ge=ge)
+    assert len(idx) == w["n"]
+    tag = f"seed {seed}: {w['n']} sequences, queries {w['m'].tolist()}, {w['matrix']} {go}/{ge}, {path}, options {opts}"
+    assert np.array_equal(got[:, :w["n"]], want), tag
+    assert np.array_equal(again[:, :w["n"]], want), tag + " (second search)"

@@ -87,3 +87,91 @@ def test_random_case_against_the_checker(seed):
     tag = f"seed {seed}: {w['n']} sequences, queries {w['m'].tolist()}, {w['matrix']} {go}/{ge}, {path}, options {opts}"
     assert np.array_equal(got[:, :w["n"]], want), tag
     assert np.array_equal(again[:, :w["n"]], want), tag + " (second search)"
+
+
+def _small_db(rng):
+    n = int(rng.choice([60, 129, 1200, 5000]))
+    L = np.clip(rng.lognormal(np.log(float(rng.choice([40, 200]))), 0.6, n), 1, 2500).astype(np.int64)
+    if rng.random() < 0.5:
+        L[rng.integers(0, n)] = int(rng.integers(1500, 6000))
+    L = np.sort(L).astype(np.uint16)
+    total = int(L.astype(np.int64).sum())
+    codes = rng.integers(0, 23, total).astype(np.int8)
+    return L, codes, np.concatenate([[0], np.cumsum(L.astype(np.int64))])
+
+
+def _batch(rng, L, codes, offs):
+    nq = int(rng.choice([1, 2, 4, 10]))
+    qlens = np.sort(np.clip(rng.lognormal(np.log(float(rng.choice([30, 300]))), 0.8, nq), 1, 1800).astype(np.int64))
+    qs = []
+    for ql in qlens:
+        q = rng.integers(0, 23, int(ql)).astype(np.int8)
+        i = int(rng.integers(0, len(L)))
+        k = int(min(L[i], ql, 200))
+        q[:k] = codes[offs[i]:offs[i] + k]
+        qs.append(q)
+    m = np.array([len(q) for q in qs], np.uint16)
+    return np.concatenate(qs), m, np.concatenate([[0], np.cumsum(m.astype(np.int64))]).astype(np.uint32)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWIMM_FUZZ_SESSIONS", "24"))))
+def test_random_session_on_one_context(seed):
+    """ONE context through a random sequence of calls -- new query batches, options flipped between searches, the database
+    cleared and replaced (eager and lazy, chunks and slabs), whole vectors and top-r -- every result against the checker:
+    what is cached between calls (work lists, launch plans, scratch, the uploader) must never outlive what it was built for."""
+    from oracle import port
+    rng = np.random.default_rng(5000 + seed)
+    keep = []
+    with hip_backend.HipSearcher(0) as s:
+        L = codes = offs = None
+        a = m = disp = None
+        mat, go, ge = "blosum62", 10, 2
+        chunks = None
+        stride = 0
+        for step in range(int(rng.integers(4, 9))):
+            what = rng.choice(["db", "queries", "option", "search"]) if L is not None and a is not None else ("db" if L is None else "queries")
+            if what == "db":
+                L, codes, offs = _small_db(rng)
+                s.clear_db()
+                if chunks is not None:
+                    keep.append(chunks)
+                    chunks = None
+                s.set_option("lazy_upload", int(rng.integers(0, 2)))
+                if rng.random() < 0.5:
+                    chunks = host.Chunks(L, codes, 128, int(rng.choice([3000, 40000, 1 << 20])))
+                    for c in chunks.chunks:
+                        s.add_chunk(c["b"], c["n"], c["disp"], 128, c["first_group"])
+                    stride = chunks.vc * 128
+                else:
+                    cuts = sorted(set([0, len(L)] + [int(x) // 128 * 128 for x in rng.integers(0, len(L) + 1, int(rng.integers(0, 4)))]))
+                    for s0, s1 in zip(cuts[:-1], cuts[1:]):
+                        s.add_sequences(L[s0:s1], codes[offs[s0]:offs[s1]], first_seq=s0)
+                    stride = (len(L) + 127) // 128 * 128
+            elif what == "queries":
+                if L is None:
+                    continue
+                a, m, disp = _batch(rng, L, codes, offs)
+                mat, go, ge = str(rng.choice(MATRICES)), int(rng.integers(1, 16)), int(rng.integers(0, 4))
+                s.set_queries(a, m, disp, submat.table(mat), go, ge)
+            elif what == "option":
+                key, vals = [("resident", [-1, 0, 1]), ("dynamic", [0, 1]), ("tail_mode", [0, 1, 2]), ("f16", [0, 1]), ("wg_limit", [0, 8]),
+                             ("bnd_mib", [1, 16384]), ("alternate", [0, 1]), ("rotate", [0, 1]), ("score_mib", [1, 32768])][int(rng.integers(0, 9))]
+                s.set_option(key, int(rng.choice(vals)))
+                continue
+            if L is None or a is None:
+                continue
+            w = {"lengths": L, "codes": codes, "offs": offs, "n": len(L), "residues": int(offs[-1]), "a": a, "m": m, "disp": disp,
+                 "query_residues": int(m.astype(np.int64).sum()), "matrix": mat}
+            want, idx = oracle_matrix(w, go=go, ge=ge)
+            tag = f"session {seed} step {step} ({what})"
+            if rng.random() < 0.5:
+                got, _ = s.search(stride)
+                assert np.array_equal(got[:, :len(L)], want), tag
+            else:
+                r = int(rng.choice([1, 5, 20, 64, 100]))
+                ts, ti, _ = s.search_topr(r, len(L))
+                for k in range(len(m)):
+                    os_, oi = port.topr(want[k], r)
+                    assert np.array_equal(ts[k][:len(os_)], os_) and np.array_equal(ti[k][:len(oi)], oi), tag + f" top-{r} of query {k}"
+    for c in keep + ([chunks] if chunks is not None else []):
+        c.close()

@@ -256,7 +256,9 @@ struct SearchRun {
     bool lane_room = false, many_short = false, alternate = false;
     uint32_t longest_cols = 0;
     std::vector<QueryPlan> qps;
-    std::vector<uint8_t> rotated;
+    std::vector<uint8_t> rotated;                            // one-pass queries that run whole (no tail kernel) on three streams in rotation
+    std::vector<uint8_t> in_batch;                           // queries of the group-resident batch launches
+    std::vector<QueryPlan> one_plan = std::vector<QueryPlan>(1);
     std::vector<std::vector<QueryPlan>> rqps;                // streaming, per-pass launches: a launch shape per (range, query)
     size_t prof_elems = 0;
     int tail_lanes = 1;                     // tail launches in flight at a time (decided with the buffer sizes)
@@ -301,7 +303,7 @@ struct SearchRun {
 int SearchRun::plan_of(size_t ri, uint32_t q, DbPlan **out)
 {
     int per_cu = 1;
-    if (wgs_per_cu(c, main_mode, qp_of(ri, q).T, qp_of(ri, q).W, c->batch_now && !rotated[q], &per_cu)) return 1;
+    if (wgs_per_cu(c, main_mode, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, &per_cu)) return 1;
     const int n_wg = n_workgroups(c, per_cu);
     if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0 || qps[q].resident, out);
     auto it = stream_plans[ri].find(n_wg);
@@ -425,14 +427,35 @@ int SearchRun::plan_queries()
     const bool rotate = many_short && c->opt_rotate && (double)longest_cols <= 2.0 * (double)c->total_cols / c->num_cu;
     prof_elems = 0;
     // Group-resident batch launches (option "resident"): ONE launch per launch shape whose items are (group, query) pairs.
-    // Every query gets the 4-wave shape that wastes the fewest padded rows at that shape's rate, and the queries of a shape
-    // run together -- short one-pass queries included: a batch is the better home for them than the rotation below (300
-    // queries of 80-120 residues against 1e8: 6 290 -> 6 600 GCUPS with one shape for all, more with a shape per query).
+    // The batch gets the 4-wave shape that wastes the fewest padded rows at that shape's rate (a query of its own shape
+    // when that saves 12 %), and the queries of a shape run together.  Which queries join depends on how small the
+    // database is beside the chip (groups per workgroup of the query's launch), measured on c2-shaped databases of 1.0e8 /
+    // 2.4e8 / 6.0e8 residues (profiles/r02_short_query_sets.txt): a query that takes several passes gains from the batch up
+    // to about 6 groups per workgroup (100 queries of 600-700 residues: 8 010 vs 7 540, 8 105 vs 7 900, 8 150 vs 8 430), a
+    // one-pass query only up to about 2 (300 of 80-120: 7 160 vs 6 290 at 1.3, 7 175 vs 7 930 at 3) -- beyond that it runs whole
+    // on one of three streams in rotation, beside the batch of the others.
+    in_batch.assign(qn, 0);
     c->batch_now = c->opt_dynamic && (c->opt_resident == 1 || (c->opt_resident < 0 && (qn >= 2 || streaming))) &&
                    !((uint64_t)qn * S > 0xFFFFFFFFull || prof_elems_bound(qm, qn) > 0xFFFFFFFFull);   // (a batch addresses score rows and profiles with 32-bit offsets)
     // (no register room is reserved for the lane-systolic waves here: among the 4-wave shapes only the 8-row one would pass that
     // filter, at 6 000 instead of 8 400 GCUPS)
     if (c->batch_now) {
+        if (choose_batch_shapes(c, main_mode, qm, qn, qps)) return 1;
+        const bool pick = c->opt_resident < 0 && !streaming;         // (forced, or a database that streams in: every query joins)
+        uint32_t joined = 0;
+        int multi_wg = 1;                                            // (the multi-pass queries join or stay out together: outside, they would bring tail kernels)
+        for (uint32_t q = 0; q < qn; ++q) {
+            int per_cu = 1;
+            if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, true, &per_cu)) return 1;
+            if (qps[q].passes > 1) multi_wg = std::max(multi_wg, n_workgroups(c, per_cu));
+        }
+        for (uint32_t q = 0; q < qn; ++q) {
+            int per_cu = 1;
+            if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, true, &per_cu)) return 1;
+            const double per_wg = (double)c->groups.size() / (qps[q].passes == 1 ? n_workgroups(c, per_cu) : multi_wg);
+            in_batch[q] = !pick || per_wg < (qps[q].passes == 1 ? 2.0 : 6.0);
+            joined += in_batch[q];
+        }
         // A batch launch is one persistent kernel for the whole batch: lane-systolic tail kernels launched beside it would
         // find no free slot until it ends (measured: c3 -16 %, a 1e8-residue database -25 %).  So a batch takes EVERY group
         // through the pipeline kernel -- which is fine as long as the longest item (longest group x the passes of the
@@ -441,43 +464,45 @@ int SearchRun::plan_queries()
         // tail kernels.
         double share = 0;
         uint32_t max_passes = 1;
-        int most_wg = 1;
-        if (choose_batch_shapes(c, main_mode, qm, qn, qps)) return 1;
         for (uint32_t q = 0; q < qn; ++q) {
+            if (!in_batch[q]) continue;
             int per_cu = 1;
             if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, true, &per_cu)) return 1;
             share += (double)qps[q].passes * (double)c->total_cols / n_workgroups(c, per_cu);
             max_passes = std::max<uint32_t>(max_passes, (uint32_t)qps[q].passes);
-            most_wg = std::max(most_wg, n_workgroups(c, per_cu));
         }
         if (dbg)
-            fprintf(stderr, "swimm_hip: batch of %u queries: longest item %u columns x %u passes, a workgroup's share %.0f column-passes, %zu groups for up to %d workgroups\n",
-                    qn, longest_cols, max_passes, share, c->groups.size(), most_wg);
+            fprintf(stderr, "swimm_hip: batch of %u of %u queries: longest item %u columns x %u passes, a workgroup's share %.0f column-passes, %zu groups\n",
+                    joined, qn, longest_cols, max_passes, share, c->groups.size());
         // (a database that streams in as several ranges: consecutive ranges overlap on two streams, the long items travel
         // and start first, and the last range is the one with the short sequences -- the longest item may take 0.9 of
         // the whole search before it sticks out at the end)
         const bool ranges_overlap = streaming && ranges.size() > 1;
-        if (c->opt_resident < 0 && (double)longest_cols * max_passes > (ranges_overlap ? 0.9 : 0.5) * share) c->batch_now = false;
-        // ... and it pays on a database that is small for the chip: with few groups per workgroup every per-pass launch fills and
-        // drains its pipelines for two or three items and ends unbalanced (1e8 residues: +13-15 %); with dozens of groups per
-        // workgroup the per-pass launches with per-query shapes are 2-3 % ahead (c5 at 10 %: 8 470 vs 8 250 GCUPS)
-        if (c->opt_resident < 0 && !streaming && c->groups.size() >= (size_t)16 * most_wg) c->batch_now = false;
+        if (c->opt_resident < 0 && (double)longest_cols * max_passes > (ranges_overlap ? 0.9 : 0.5) * share) joined = 0;
+        if (pick && joined < 2) joined = 0;                          // (one query alone gains nothing from a batch launch)
+        if (joined == 0) { c->batch_now = false; in_batch.assign(qn, 0); }
     }
     if (dbg) fprintf(stderr, "swimm_hip: batch decided %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
-    // No batch, eight or more short queries: those that fit one pass run whole -- every group through the pipeline kernel,
-    // no tail kernel -- on three streams in rotation (issue()); a long sequence's serial chain, which bounds a lone short
-    // query, is then covered by the neighbours' work.
-    if (!c->batch_now && rotate)
+    // The one-pass queries outside the batch run whole -- every group through the pipeline kernel, no tail kernel -- on
+    // three streams in rotation (issue()) when there are eight or more of them (a long sequence's serial chain, which
+    // bounds a lone short query, is then covered by the neighbours' work), and always beside a batch (tail kernels would
+    // find no room).  They are planned with the per-pass kernel's registers.
+    const bool batch_formed = c->batch_now;
+    c->batch_now = false;
+    if (rotate || batch_formed)
         for (uint32_t q = 0; q < qn; ++q)
-            if (qm[q] <= 64 * kLaneRows) rotated[q] = choose_plan(c, main_mode, qm[q], false, true, &qps[q]) == 0;   // fails when no one-pass shape exists
+            if (!in_batch[q] && qm[q] <= 64 * kLaneRows) {
+                rotated[q] = choose_plan(c, main_mode, qm[q], false, true, &qps[q]) == 0;   // fails when no one-pass shape exists
+                if (!rotated[q] && batch_formed) { in_batch[q] = 1; if (choose_batch_shapes(c, main_mode, qm + q, 1, one_plan)) return 1; qps[q] = one_plan[0]; }   // ... then it stays in the batch
+            }
     std::vector<BulkCols> rbulk;
-    if (streaming && !c->batch_now && ranges.size() > 1) {
+    if (streaming && !batch_formed && ranges.size() > 1) {
         rqps.assign(ranges.size(), std::vector<QueryPlan>(qn));
         rbulk.resize(ranges.size());
         for (size_t ri = 0; ri < ranges.size(); ++ri) bulk_cols_of(c, ranges[ri], rbulk[ri]);
     }
     for (uint32_t q = 0; q < qn; ++q) {
-        if (!c->batch_now && !rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;   // (a batch's shapes are chosen above)
+        if (!in_batch[q] && !rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;   // (a batch's shapes are chosen above)
         if (dbg)
             fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
         // A database that is streaming in, per-pass launches: every range gets the launch shape that suits ITS groups -- the
@@ -498,8 +523,9 @@ int SearchRun::plan_queries()
     // of its own), so that the end of every launch -- the last workgroups finishing alone -- is covered by a kernel of
     // the other query.  (Within ONE such query the even/odd split of run_passes does the same.)
     uint32_t n_multi = 0;
-    for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && qps[q].passes > 1;
+    for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && !in_batch[q] && qps[q].passes > 1;
     alternate = n_multi >= 2 && c->opt_alternate && !streaming;
+    c->batch_now = batch_formed;
     return 0;
 }
 
@@ -514,7 +540,7 @@ int SearchRun::upload_profiles()
         }
     }
     c->last_plans.resize(c->qm.size());
-    for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = c->batch_now && !rotated[q]; c->last_plans[qb + q] = qps[q]; }
+    for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = in_batch[q] != 0; c->last_plans[qb + q] = qps[q]; }
     for (auto &rv : rqps)
         for (uint32_t q = 0; q < qn; ++q) {
             rv[q].mpad = qps[q].mpad; rv[q].prof_off = qps[q].prof_off;      // one profile per query, padded for the tallest plan
@@ -560,7 +586,7 @@ int SearchRun::size_buffers()
                     const QueryPlan &qp = qp_of(ri, q);
                     if (qp.passes <= 1) { launch_total += 2; continue; }
                     int per_cu = 1;
-                    if (wgs_per_cu(c, main_mode, qp.T, qp.W, c->batch_now && !rotated[q], &per_cu)) return 1;
+                    if (wgs_per_cu(c, main_mode, qp.T, qp.W, in_batch[q] != 0, &per_cu)) return 1;
                     const uint64_t cols = ranges[ri].cols * (main_mode == Mode::I32 ? 2 : 1);
                     if (qps[q].resident) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_all * 64);   // (a batch takes every group)
                     // (only the dynamic queue's list is cut into runs that fit the budget: the static partition takes the range whole)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Batches of short queries against a small database (1e8 residues, c2-shaped): the regime where a single long
-sequence's serial chain is longer than a query's whole bulk work.  usage: python tools/short_query_bench.py"""
+sequence's serial chain is longer than a query's whole bulk work.  usage: [SQ_SCALE=0.17] [SQ_MEDIUM=1] [SWIMM_HIP_OPTIONS=...] python tools/short_query_bench.py"""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from swimm_amd import hip_backend, host, submat, synth  # noqa: E402
 
-L = np.sort(synth.config_lengths("c2", 0.17)).astype(np.uint16)
+L = np.sort(synth.config_lengths("c2", float(os.environ.get("SQ_SCALE", "0.17")))).astype(np.uint16)
 total = int(L.astype(np.int64).sum())
 codes = host.recode(synth.residues(2, 7, 0, total))
 rng = np.random.default_rng(1)

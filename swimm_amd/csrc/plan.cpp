@@ -171,8 +171,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
         const int T = 8 + 4 * ti;
         if (c->opt_T && T != c->opt_T) continue;
         if (!pipe_has_variant(mode, T)) continue;
-        if (T == 28 && !c->opt_T && resident_for(c, 2)) continue;   // the group-resident 28-row kernel does not fit 128 VGPRs (16 spilled)
-        int maxW = (T > 28) ? 12 : 16;        // __launch_bounds__ of the instantiations
+        int maxW = (T > 28 || (T == 28 && resident_for(c, 2))) ? 12 : 16;        // __launch_bounds__ of the instantiations (the group-resident 28-row kernel needs 137 VGPRs)
         if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
         const int strips = std::max(1, (m + T - 1) / T);
         for (int W = 1; W <= maxW; ++W) {
@@ -238,8 +237,7 @@ int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_
         const int T = 8 + 4 * ti;
         if (c->opt_T && T != c->opt_T) continue;
         if (!pipe_has_variant(mode, T)) continue;
-        if (T == 28 && !c->opt_T) continue;                       // the group-resident 28-row kernel does not fit 128 VGPRs
-        Wof[ti] = c->opt_W > 0 ? std::min(c->opt_W, T > 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
+        Wof[ti] = c->opt_W > 0 ? std::min(c->opt_W, T >= 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
         ok[ti] = true;
         for (uint32_t q = 0; q < qn; ++q) cost[ti] += rows_of(qm[q], T, Wof[ti]) / kShapeGcups[ti][Wof[ti] - 1];
     }

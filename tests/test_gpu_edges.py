@@ -117,6 +117,7 @@ def test_every_strip_height_vs_oracle(T):
     for W in (1, 3, 4):
         run_case(seqs, queries, opts={"rows_per_wave": T, "waves": W, "tail_mode": 2})
     run_case(seqs, queries, opts={"rows_per_wave": T})
+    run_case(seqs, queries, opts={"rows_per_wave": T, "waves": 4, "resident": 1})      # the group-resident instantiation of every height
 
 
 def test_mass_promotion():

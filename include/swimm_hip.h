@@ -147,6 +147,8 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    valid until that search has returned.  swimm_hip_search_chunks always works this way.  The copies
  *                    are made by a thread the context owns (started with the first recorded chunk, parked between
  *                    searches, joined by swimm_hip_destroy); the calls of one context still come from one thread at a time.
+ *   "upload_piece_kib"  with lazy_upload, chunks and slabs larger than this are recorded in pieces of about this size (default
+ *                    98304 = 96 MiB), so that a database handed over as one buffer still streams in as several ranges
  *   "lane_acquire"   0 = default: chained lane-systolic passes read their predecessor's boundary rows with sc1 loads behind a
  *                    relaxed poll; 1 = an agent-scope acquire after every poll as well (A/B option)
  *   "score_mib"      HBM budget of the score rows (4 B per query and sequence): the query list is walked in batches

@@ -262,6 +262,7 @@ struct SearchRun {
     std::vector<std::vector<QueryPlan>> rqps;                // streaming, per-pass launches: a launch shape per (range, query)
     size_t prof_elems = 0;
     int tail_lanes = 1;                     // tail launches in flight at a time (decided with the buffer sizes)
+    double stream_free[3] = {0, 0, 0};      // streaming, group-resident ranges: when each of the three streams is expected to have drained (s after t_begin)
 
     SearchRun(swimm_hip_ctx *ctx, uint32_t b, uint32_t e) : c(ctx), qb(b), qe(e) {}
     ~SearchRun()
@@ -778,7 +779,21 @@ int SearchRun::issue()
                 for (uint32_t q : kv.second) { pass_sum += qps[q].passes; max_p = std::max<uint32_t>(max_p, qps[q].passes); }
                 // (a database that streams in: three ranges in flight, each on a stream and a boundary scratch of its own --
                 // no tail kernels beside group-resident launches, so the tail stream serves as the third)
-                const uint32_t si = streaming ? (uint32_t)((bi + ri) % 3) : (bi & 1);
+                // Which of the three: the one expected to be free first.  A launch lasts as long as its longest item's chain
+                // (the longest group x the passes of the longest query at 1.2 us per column-pass: 18 ms for 5 000 columns x 3)
+                // or its share of the chip's time, whichever is longer; a range that queued behind the range with the long
+                // chains would wait for them with its data long there.
+                uint32_t si = bi & 1;
+                if (streaming) {
+                    const double now = now_s() - t_begin;
+                    uint32_t longest = 0;
+                    for (uint32_t g = ranges[ri].g0; g < ranges[ri].g1; ++g) longest = std::max(longest, c->groups[g].ncols);
+                    const double lasts = std::max(1.2e-6 * longest * max_p, (double)ranges[ri].cols * kGroupSeqs * (double)(pass_sum * T * W) / 8000e9);
+                    si = 0;
+                    for (uint32_t k = 1; k < 3; ++k)
+                        if (std::max(now, stream_free[k]) < std::max(now, stream_free[si])) si = k;
+                    stream_free[si] = std::max(now, stream_free[si]) + lasts;
+                }
                 hipStream_t st = si == 0 ? c->stream : si == 1 ? c->stream_b : c->stream2;
                 DevBuf<uint2> &bnd = si == 0 ? c->d_bnd : si == 1 ? c->d_bnd_b : c->d_bnd_c;
                 if (run_resident_batch(c, main_mode, T, W, dp->main, c->d_qdesc.p + off, nqb, pass_sum, max_p, st, bnd)) return 1;

@@ -142,21 +142,15 @@ int swimm_hip_set_queries(swimm_hip_ctx *c, const char *a, const uint16_t *m, co
     return 0;
 }
 
-int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint16_t *n, const uint32_t *b_disp,
-                        uint32_t group_count, uint32_t vl, uint64_t first_group)
+// one chunk, or one piece of a caller's chunk (own_disp: the piece's offsets, counted from its first byte)
+static int add_chunk_piece(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint16_t *n, const uint32_t *b_disp, std::vector<uint32_t> own_disp,
+                           uint32_t group_count, uint32_t vl, uint64_t first_group)
 {
-    if (!c || !b || !n || !b_disp) return fail("swimm_hip_add_chunk: NULL argument");
-    if (group_count == 0) return fail("swimm_hip_add_chunk: empty chunk");
-    if (vl == 0 || vl > (uint32_t)kGroupSeqs || kGroupSeqs % vl != 0)
-        return fail("swimm_hip_add_chunk: lane width %u must divide %d", vl, kGroupSeqs);
-    if (vD > 0xFFFFFFFFull) return fail("swimm_hip_add_chunk: chunk larger than 4 GiB");
-    for (uint32_t g = 0; g < group_count; ++g)
-        if ((uint64_t)b_disp[g] + (uint64_t)n[g] * vl > vD)
-            return fail("swimm_hip_add_chunk: group %u (disp %u, n %u) runs past vD=%llu", g, b_disp[g], n[g], (unsigned long long)vD);
-    HIP_TRY(hipSetDevice(c->device));
     const uint32_t per = kGroupSeqs / vl;
     ChunkRec rec;
     rec.kind = 0;
+    rec.own_disp = std::move(own_disp);
+    if (!rec.own_disp.empty()) b_disp = rec.own_disp.data();      // (a vector's storage survives the moves of the record)
     rec.h_b = b; rec.vD = vD; rec.h_n = n; rec.h_disp = b_disp; rec.group_count = group_count; rec.vl = vl;
     rec.n_groups = (group_count + per - 1) / per;
     rec.goff.resize(rec.n_groups);
@@ -174,11 +168,75 @@ int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint
     return 0;
 }
 
+int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint16_t *n, const uint32_t *b_disp,
+                        uint32_t group_count, uint32_t vl, uint64_t first_group)
+{
+    if (!c || !b || !n || !b_disp) return fail("swimm_hip_add_chunk: NULL argument");
+    if (group_count == 0) return fail("swimm_hip_add_chunk: empty chunk");
+    if (vl == 0 || vl > (uint32_t)kGroupSeqs || kGroupSeqs % vl != 0)
+        return fail("swimm_hip_add_chunk: lane width %u must divide %d", vl, kGroupSeqs);
+    if (vD > 0xFFFFFFFFull) return fail("swimm_hip_add_chunk: chunk larger than 4 GiB");
+    for (uint32_t g = 0; g < group_count; ++g)
+        if ((uint64_t)b_disp[g] + (uint64_t)n[g] * vl > vD)
+            return fail("swimm_hip_add_chunk: group %u (disp %u, n %u) runs past vD=%llu", g, b_disp[g], n[g], (unsigned long long)vD);
+    HIP_TRY(hipSetDevice(c->device));
+    // A chunk that will stream in (lazy_upload) is recorded in pieces of about upload_piece_kib (default 96 MiB, the
+    // reference's chunk size): a caller that hands over its database as one 0.6 GB buffer still gets ranges that overlap
+    // copy and alignment.  (Finer pieces do not pay: with 32 MiB the first kernel starts 1.5 ms sooner, but the search
+    // takes seven ranges instead of four and ends no earlier -- 31.5 vs 31.0 ms through chunks, 36.4 vs 32.4 through slabs.)
+    // Pieces are runs of whole device groups whose bytes are contiguous in the caller's buffer.
+    const uint64_t piece = (uint64_t)c->opt_upload_piece_kib << 10;
+    const uint32_t per = kGroupSeqs / vl;
+    bool ascending = true;
+    for (uint32_t g = 1; g < group_count; ++g) ascending = ascending && b_disp[g] >= b_disp[g - 1];
+    if (!c->opt_lazy_upload || vD <= piece + piece / 2 || !ascending)
+        return add_chunk_piece(c, b, vD, n, b_disp, {}, group_count, vl, first_group);
+    for (uint32_t g0 = 0; g0 < group_count;) {
+        uint32_t g1 = g0;
+        uint64_t end = b_disp[g0];
+        do {
+            g1 = std::min(group_count, g1 + per);
+            for (uint32_t g = g1 - std::min(per, g1 - g0); g < g1; ++g) end = std::max<uint64_t>(end, (uint64_t)b_disp[g] + (uint64_t)n[g] * vl);
+        } while (g1 < group_count && end - b_disp[g0] < piece);
+        std::vector<uint32_t> disp(g1 - g0);
+        for (uint32_t g = g0; g < g1; ++g) disp[g - g0] = b_disp[g] - b_disp[g0];
+        if (add_chunk_piece(c, b + b_disp[g0], end - b_disp[g0], n + g0, nullptr, std::move(disp), g1 - g0, vl, first_group + g0)) return 1;
+        g0 = g1;
+    }
+    return 0;
+}
+
+static int add_sequences_piece(swimm_hip_ctx *c, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq);
+
 int swimm_hip_add_sequences(swimm_hip_ctx *c, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq)
 {
     if (!c || !lengths || !codes) return fail("swimm_hip_add_sequences: NULL argument");
     if (n_seq == 0) return fail("swimm_hip_add_sequences: empty slab");
     if (n_seq > 0x7FFFFFFFull) return fail("swimm_hip_add_sequences: more than 2^31 sequences in one slab");
+    if (!c->opt_lazy_upload) return add_sequences_piece(c, lengths, codes, n_seq, first_seq);
+    // (lazy_upload: pieces of about upload_piece_kib, whole device groups each -- see swimm_hip_add_chunk)
+    const uint64_t piece = (uint64_t)c->opt_upload_piece_kib << 10;
+    uint64_t off = 0;
+    for (uint64_t s0 = 0; s0 < n_seq;) {
+        uint64_t s1 = s0, bytes = 0;
+        do {
+            const uint64_t e = std::min<uint64_t>(n_seq, s1 + kGroupSeqs);
+            for (uint64_t i = s1; i < e; ++i) bytes += lengths[i];
+            s1 = e;
+        } while (s1 < n_seq && bytes < piece);
+        if (n_seq - s1 < (uint64_t)kGroupSeqs * 4 && bytes < piece + piece / 2) {          // (no sliver at the end)
+            for (uint64_t i = s1; i < n_seq; ++i) bytes += lengths[i];
+            s1 = n_seq;
+        }
+        if (add_sequences_piece(c, lengths + s0, codes + off, s1 - s0, first_seq + s0)) return 1;
+        off += bytes;
+        s0 = s1;
+    }
+    return 0;
+}
+
+static int add_sequences_piece(swimm_hip_ctx *c, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq)
+{
     ChunkRec rec;
     rec.kind = 1;
     rec.off.resize(n_seq + 1);
@@ -431,6 +489,9 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "lazy_upload")) {
         c->opt_lazy_upload = value != 0;
+    } else if (!strcmp(key, "upload_piece_kib")) {
+        if (value < 16) return fail("upload_piece_kib must be >= 16");
+        c->opt_upload_piece_kib = value;
     } else if (!strcmp(key, "lane_acquire")) {
         c->opt_lane_acquire = value != 0;
     } else if (!strcmp(key, "wg_limit")) {

@@ -125,6 +125,7 @@ struct ChunkRec {
     // MICsearch.c:85-91), so they must stay valid until that search has returned.
     int kind = 0;               // 0 = reference chunk layout (re-tile), 1 = .seq slab (tile)
     const char *h_b = nullptr; uint64_t vD = 0; const uint16_t *h_n = nullptr; const uint32_t *h_disp = nullptr;
+    std::vector<uint32_t> own_disp;   // a piece of a caller's chunk: its groups' offsets counted from the piece's first byte (h_disp points here)
     uint32_t group_count = 0, vl = 0;
     const char *h_codes = nullptr; uint64_t code_bytes = 0;
     std::vector<uint32_t> off;  // kind 1: residue offset of every sequence (n_seq + 1)
@@ -154,6 +155,7 @@ struct swimm_hip_ctx {
     hipStream_t stream_up = nullptr;    // uploads: H2D copies, (re-)tile kernels, work lists -- never waits for a DP kernel
     hipEvent_t ev_copied = nullptr;
     DevBuf<uint8_t> up_b; DevBuf<uint16_t> up_n; DevBuf<uint32_t> up_disp, up_gcols, up_off; DevBuf<uint64_t> up_goff;   // upload scratch, reused chunk after chunk
+    int opt_upload_piece_kib = 98304;   // lazy_upload: chunks and slabs larger than this are recorded in pieces of about this size (96 MiB, the reference's chunk size)
     int opt_lazy_upload = 0;            // 1: add_chunk / add_sequences record the caller's buffers, the first search streams them in
     hipStream_t stream3 = nullptr;      // promotion re-runs
     hipEvent_t ev_ready = nullptr, ev_tail3 = nullptr;

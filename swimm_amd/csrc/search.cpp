@@ -341,7 +341,7 @@ int SearchRun::layout_ranges()
 {
     // Chunks whose bytes are still on the host (option "lazy_upload"): this search streams them in -- chunk k+1 is
     // copied and tiled on the upload stream while chunk k is being aligned (X2 overlapped with compute,
-    // MICsearch.c:85-91) -- and every chunk is then one range with work lists of its own.  Otherwise the whole resident
+    // MICsearch.c:85-91) -- as a few ranges of consecutive chunks, each with work lists of its own.  Otherwise the whole resident
     // database is one range with cached work lists.
     streaming = false;
     for (const ChunkRec &r : c->chunks) streaming = streaming || !r.uploaded;
@@ -810,7 +810,8 @@ int SearchRun::issue()
         if (dbg && streaming) fprintf(stderr, "swimm_hip: range %zu: next range's work lists built %.3f ms after the call began\n", ri, (now_s() - t_begin) * 1e3);
     }
     if (streaming) {
-        // the ranges alternated between the two bulk streams: "query q's bulk kernels are done" = both have drained
+        // the ranges took turns on the bulk streams (and the tail stream, for group-resident launches): "query q's bulk
+        // kernels are done" = all of them have drained
         HIP_TRY(hipEventRecord(c->ev_b, c->stream_b));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_b, 0));
         HIP_TRY(hipEventRecord(c->ev_a, c->stream2));

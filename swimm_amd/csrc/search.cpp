@@ -668,7 +668,8 @@ int SearchRun::issue()
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
     for (int i = 0; i + 1 < tail_lanes; ++i) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], c->ev_ready, 0));
     HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_ready, 0));
-    uint32_t one_pass_seen = 0, multi_seen = 0, tail_seen = 0;
+    uint32_t one_pass_seen = 0, tail_seen = 0;
+    double alt_rows[2] = {0, 0};
     HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
     while (c->ev_query.size() < 2 * (size_t)qn) {
         hipEvent_t e;
@@ -744,7 +745,13 @@ int SearchRun::issue()
             DevBuf<uint2> *bnd = &c->d_bnd;
             // (the one-pass queries of such a batch take their turn as well: they are the shortest, the batch ends with them,
             // and a launch that runs alone ends with a few workgroups holding the chip -- c3's last eight queries: 26 ms at 5 900 GCUPS)
-            if (alternate && !rotated[q] && !qps[q].resident && !(many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows) && (multi_seen++ & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
+            // Each query goes to the stream with less work so far (padded rows), longest first: strict turns left one stream
+            // 6 % more rows on c3 and the other idle for the last 60 ms.
+            if (alternate && !rotated[q] && !qps[q].resident && !(many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows)) {
+                const int pick = alt_rows[1] < alt_rows[0];
+                alt_rows[pick] += (double)qps[q].passes * qps[q].W * qps[q].T;
+                if (pick) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
+            }
             if (streaming && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
             // (the tail's first tier is the bulk's: binary16 pairs, unless that tier is switched off; the ladder below re-runs
             // what reaches 2048 in int16 -- rare, the chains are long but the scores are not)
@@ -755,6 +762,10 @@ int SearchRun::issue()
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
                 continue;
             }
+            if (dbg)
+                fprintf(stderr, "swimm_hip: query %u (%u rows, %d passes of %d x %d): bulk on %s, tail on %s\n", q, qm[q], qp_of(ri, q).passes, qp_of(ri, q).W, qp_of(ri, q).T,
+                        bulk_stream == c->stream ? "stream A" : bulk_stream == c->stream_b ? "stream B" : "the tail stream",
+                        tail_stream == c->stream2 ? "the tail stream" : tail_stream == c->stream ? "stream A" : tail_stream == c->stream_b ? "stream B" : "a further tail stream");
             if (dp->have_main && run_passes(c, main_mode, qp_of(ri, q), dp->main, row, bulk_stream, !streaming && !alternate, *bnd)) return 1;
             if (ri + 1 == ranges.size()) {
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));

@@ -401,11 +401,11 @@ int make_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool no_tail, const Rang
             for (uint32_t l = 0; l < 64; ++l) {
                 // a pair only runs to the end of its longer member, not to the end of the group (when the lengths are
                 // already known: a chunk that is still streaming in runs to the end of its group -- padding scores 0)
-                const uint32_t len = exact_lengths ? std::max(c->seq_len[gd.seq0 + l], c->seq_len[gd.seq0 + 64 + l]) : gd.ncols;
+                const uint32_t len = exact_lengths ? std::max(c->seq_len[gd.seq0 + 2 * l], c->seq_len[gd.seq0 + 2 * l + 1]) : gd.ncols;
                 if (len == 0) continue;                 // empty pair: scores stay 0
                 LaneItem li{};
                 li.db = gd.db; li.lane = l; li.half = 0; li.ncols = (len + kChunkCols - 1) / kChunkCols * kChunkCols;
-                li.slot_a = gd.seq0 + l; li.slot_b = gd.seq0 + 64 + l;
+                li.slot_a = gd.seq0 + 2 * l; li.slot_b = gd.seq0 + 2 * l + 1;
                 tail.push_back(li);
             }
         }

@@ -893,16 +893,16 @@ int SearchRun::promotion_ladder()
                 std::vector<LaneItem> items;
                 std::vector<uint8_t> seen;
                 for (uint32_t slot : list) {                      // re-run the packed PAIR the slot belongs to
-                    const uint32_t g = slot / kGroupSeqs, l = slot % 64;
+                    const uint32_t g = slot / kGroupSeqs, l = (slot % kGroupSeqs) / 2;      // lane l holds the group's sequences 2l and 2l + 1
                     const uint32_t pair = g * 64 + l;
                     if (seen.size() <= pair) seen.resize(pair + 1, 0);
                     if (seen[pair]) continue;
                     seen[pair] = 1;
                     const GroupDesc &gd = c->groups[g];
-                    const uint32_t len = std::max(c->seq_len[gd.seq0 + l], c->seq_len[gd.seq0 + 64 + l]);
+                    const uint32_t len = std::max(c->seq_len[gd.seq0 + 2 * l], c->seq_len[gd.seq0 + 2 * l + 1]);
                     LaneItem li{};
                     li.db = gd.db; li.lane = l; li.half = 0; li.ncols = (len + kChunkCols - 1) / kChunkCols * kChunkCols;
-                    li.slot_a = gd.seq0 + l; li.slot_b = gd.seq0 + 64 + l;
+                    li.slot_a = gd.seq0 + 2 * l; li.slot_b = gd.seq0 + 2 * l + 1;
                     if (li.ncols) items.push_back(li);
                 }
                 c->promoted16 += list.size();
@@ -914,7 +914,7 @@ int SearchRun::promotion_ladder()
             for (uint32_t slot : list) {
                 const uint32_t g = slot / kGroupSeqs, within = slot % kGroupSeqs;
                 LaneItem li{};
-                li.db = c->groups[g].db; li.lane = within % 64; li.half = within / 64;
+                li.db = c->groups[g].db; li.lane = within / 2; li.half = within % 2;
                 li.ncols = (c->seq_len[slot] + kChunkCols - 1) / kChunkCols * kChunkCols;
                 li.slot_a = slot; li.slot_b = 0;
                 if (li.ncols) items.push_back(li);

@@ -15,7 +15,7 @@ constexpr int kMaxWaves = 16;     // waves per workgroup (1024 threads)
 struct GroupDesc {
     const uint8_t *db;   // tiled residues of this group
     uint32_t ncols;      // padded length, multiple of kChunkCols
-    uint32_t seq0;       // local score slot of lane 0 (half A); half B starts at seq0 + 64
+    uint32_t seq0;       // local score slot of lane 0's sequence A; lane l holds the slots seq0 + 2l (A) and seq0 + 2l + 1 (B)
 };
 
 // One unit of work for a workgroup's pipeline: self-contained (32 bytes, one scalar load), so that starting a group
@@ -23,9 +23,9 @@ struct GroupDesc {
 struct Item {
     const uint8_t *db;   // tiled residues of the group
     uint32_t ncols;      // padded length, multiple of kChunkCols
-    uint32_t seq0;       // packed tiers: local score slot of lane 0 (half A); half B starts at seq0 + 64
+    uint32_t seq0;       // local score slot of lane 0's sequence A; lane l holds the slots seq0 + 2l (A) and seq0 + 2l + 1 (B)
     uint32_t half;       // int32 tier only: 0 = sequences 0..63 of the group, 1 = 64..127
-    uint32_t out_slot;   // int32 tier only: results go to out[out_slot*64 + lane]
+    uint32_t out_slot;   // (unused: the int32 tier writes out[seq0 + 2*lane + half])
     uint64_t bnd_off;    // first column of this item in the pass-boundary buffer
 };
 

@@ -328,7 +328,7 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
 #pragma unroll
     for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
 
-    uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, out_slot = 0, n = 0, next_it = kNoItem;
+    uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, n = 0, next_it = kNoItem;
     uint32_t pass = 0, len = 0;            // RES: pass of the current item; steps the item-pass occupies (>= nch)
     // RES: an item is a (group, query) pair -- item id v = group rank * n_queries + (n_queries - 1 - query), queries longest
     // first within a group -- so one launch takes a whole batch of queries that share the launch shape; a single multi-pass
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
                 const uint32_t gi = RES ? vi / nq : vi;
                 const Item iv = load_item(p.items, gi);
                 nch = iv.ncols / C; dbp = iv.db; seq0 = iv.seq0;
-                half = iv.half; out_slot = iv.out_slot;
+                half = iv.half;
                 bnd_off = RES ? (uint64_t)blockIdx.x * p.bnd_wg_cols : iv.bnd_off;
                 if (RES && pass == 0) {               // a new (group, query) item: the query's parameters, one scalar load
                     cur_q = nq - 1 - (vi - gi * nq);
@@ -566,14 +566,14 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
             if (scored) {   // item(-pass) finished: every strip contributes its best (CPUsearch.c:670-676)
                 if (M == 2) {
                     const v2h b2 = __builtin_bit_cast(v2h, Ops::bits(best));
-                    atomicMax(q_out + seq0 + lane, (int)(float)b2.x);
-                    atomicMax(q_out + seq0 + 64 + lane, (int)(float)b2.y);
+                    atomicMax(q_out + seq0 + 2 * lane, (int)(float)b2.x);          // a lane's pair = two neighbours of the sorted database
+                    atomicMax(q_out + seq0 + 2 * lane + 1, (int)(float)b2.y);
                 } else if (PK) {
                     const v2s b2 = __builtin_bit_cast(v2s, Ops::bits(best));
-                    atomicMax(q_out + seq0 + lane, (int)b2.x);
-                    atomicMax(q_out + seq0 + 64 + lane, (int)b2.y);
+                    atomicMax(q_out + seq0 + 2 * lane, (int)b2.x);
+                    atomicMax(q_out + seq0 + 2 * lane + 1, (int)b2.y);
                 } else {
-                    atomicMax(q_out + (size_t)out_slot * 64 + lane, (int)Ops::bits(best));
+                    atomicMax(q_out + seq0 + 2 * lane + half, (int)Ops::bits(best));
                 }
             }
             if (++cc >= len) {
@@ -1025,7 +1025,10 @@ hipError_t launch_lane(Mode mode, int rows_per_lane, int n_wg, const LaneParams 
 
 // ---- re-tile: reference chunk layout -> device groups --------------------------------------
 // reference byte of VL-group v, position j, lane kk: b[disp[v] + j*vl + kk]   (sequences.c:508-513)
-// device dword of group g, chunk c, lane l: tiled[goff[g] + (c*64 + l)*8 + {0: seq l, 4: seq 64+l}]
+// device dword of group g, chunk c, lane l: tiled[goff[g] + (c*64 + l)*8 + {0: seq 2l, 4: seq 2l+1}] -- a lane's pair are
+// NEIGHBOURS of the length-sorted database, so the lane-systolic kernel (one wave per pair, run to the longer member's
+// end) wastes nothing on the pair's shorter member: with (l, 64+l) the pairs of c3's three longest groups were 1.76 M
+// columns, with neighbours 1.07 M.
 __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__restrict__ n,
                               const uint32_t *__restrict__ disp, uint32_t vl_groups, uint32_t vl,
                               const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols,
@@ -1043,7 +1046,7 @@ __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__r
         uint32_t w[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const uint32_t sl = l + 64 * hh;          // sequence within the device group
+            const uint32_t sl = 2 * l + hh;           // sequence within the device group
             const uint32_t v = g * per + sl / vl, kk = sl % vl;
             uint32_t word = 0, real_end = 0;
 #pragma unroll
@@ -1086,7 +1089,7 @@ hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *di
 // The direct path of the `swimm` program: the concatenated residue codes and their offsets go to the GPU as they
 // are and the device builds its own layout, instead of the host interleaving lanes first (sequences.c:506-526)
 // and retile_kernel undoing it.  Group g holds sequences 128 g .. 128 g + 127 of the slab; lane l of chunk c gets
-// columns 4c..4c+3 of sequence l (low dword) and of sequence 64 + l (high dword), code 24 past a sequence's end.
+// columns 4c..4c+3 of sequence 2l (low dword) and of sequence 2l + 1 (high dword), code 24 past a sequence's end.
 __global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const uint32_t *__restrict__ seq_off, uint32_t n_seq,
                                       const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols,
                                       uint8_t *__restrict__ tiled)
@@ -1099,7 +1102,7 @@ __global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const u
         uint32_t w[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const uint32_t s = g * kGroupSeqs + l + 64 * hh;
+            const uint32_t s = g * kGroupSeqs + 2 * l + hh;
             uint32_t word = 0x18181818u;              // four padding codes (24)
             if (s < n_seq) {
                 const uint32_t b0 = seq_off[s], len = seq_off[s + 1] - b0;

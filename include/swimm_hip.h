@@ -126,7 +126,9 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    0 = packed int16 first tier
  *   "force_i32"      1 = everything in int32 (one sequence per lane)
  *   "tail_mode"      0 = auto: unusually long groups go through the lane-systolic kernel, 1 = every group, 2 = none
- *   "tail_frac"      a group is "unusually long" above this percentage of a CU's mean load (default 50)
+ *   "tail_frac"      a group is "unusually long" above this percentage of a CU's mean load (default 30) ...
+ *   "tail_cap"       ... and joins the lane-systolic tail as long as the tail stays below this many per mille of the search's cells
+ *                    (default 25; 0 = no cap)
  *   "dynamic"        1 = default: workgroups pull groups from a global queue; 0 = static longest-first partition
  *   "lane_rows"      1 = default: one-pass lane-systolic launches of short queries use 2 / 4 query rows per lane; 0 = always 8
  *   "resident"       0 = default: one launch per pass of a multi-pass query ("split", "bnd_mib" apply); 1 = ONE launch, each

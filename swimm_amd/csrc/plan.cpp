@@ -375,12 +375,24 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> 
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->groups[rg.g0 + a].ncols > c->groups[rg.g0 + b].ncols; });
     uint64_t rest = rg.cols;
-    // the yardstick is the load of a CU, however many workgroups share it
+    // The yardstick is the load of a CU, however many workgroups share it -- and the lane-systolic kernel must stay a side
+    // show: it aligns a cell at 1.5x the pipeline kernel's instructions and, beside the bulk waves, at a tenth of its rate,
+    // so the tail takes at most tail_cap per mille of the search's cells (pairs run to their longer member).  Measured
+    // (profiles/r02_tail_fraction.txt): c3 at full size is best at 30 % / 2.5 % of the cells (8 180 GCUPS; 7 910 at 50 % /
+    // 1.1 %, 7 750 at 20 % / 9 %), c3 at 30 % of its size at 2.5-7 % (6 170-6 190; 4 900 at 29 %, 2 300 at 93 %).
+    const double cap = c->opt_tail_cap > 0 ? (double)rg.cols * kGroupSeqs * (c->opt_tail_cap + 0.5) * 1e-3 : 1e300;
+    double tail_cells = 0;
     for (uint32_t g : order) {
+        const GroupDesc &gd = c->groups[rg.g0 + g];
         const double mean = (double)rest / c->num_cu;
-        if ((double)c->groups[rg.g0 + g].ncols <= c->opt_tail_frac * 0.01 * mean) break;
+        if ((double)gd.ncols <= c->opt_tail_frac * 0.01 * mean) break;
+        double cells = 0;
+        for (uint32_t l = 0; l < 64; ++l) cells += 2.0 * std::max(c->seq_len[gd.seq0 + 2 * l], c->seq_len[gd.seq0 + 2 * l + 1]);
+        if (cells == 0) cells = 128.0 * gd.ncols;          // (a chunk whose true lengths the re-tile kernel has yet to report: the group's)
+        if (tail_cells + cells > cap) break;
+        tail_cells += cells;
         is_tail[g] = 1;
-        rest -= c->groups[rg.g0 + g].ncols;
+        rest -= gd.ncols;
     }
     return is_tail;
 }

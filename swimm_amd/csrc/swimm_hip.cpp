@@ -463,6 +463,10 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         if (value < 1 || value > 1000) return fail("tail_frac must be 1..1000 (percent of a CU's mean load)");
         c->opt_tail_frac = value;
         release_plans(c);
+    } else if (!strcmp(key, "tail_cap")) {
+        if (value < 0 || value > 1000) return fail("tail_cap must be 0..1000 (per mille of the cells; 0 = no cap)");
+        c->opt_tail_cap = value;
+        release_plans(c);
     } else if (!strcmp(key, "rotate")) {
         c->opt_rotate = value != 0;
     } else if (!strcmp(key, "lane_rows")) {

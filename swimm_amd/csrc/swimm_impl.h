@@ -167,7 +167,8 @@ struct swimm_hip_ctx {
     int opt_force_i32 = 0;              // 1: everything in int32
     int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
-    int opt_tail_frac = 50;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load
+    int opt_tail_frac = 30;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load ...
+    int opt_tail_cap = 25;              // ... as long as the tail stays below this many per mille of the search's cells (0 = no cap)
     int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
     int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
     int opt_resident = -1;              // group-resident batch launches: -1 = when the batch has two or more queries that are not rotated, 0 never, 1 always

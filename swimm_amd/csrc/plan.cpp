@@ -389,7 +389,9 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> 
         double cells = 0;
         for (uint32_t l = 0; l < 64; ++l) cells += 2.0 * std::max(c->seq_len[gd.seq0 + 2 * l], c->seq_len[gd.seq0 + 2 * l + 1]);
         if (cells == 0) cells = 128.0 * gd.ncols;          // (a chunk whose true lengths the re-tile kernel has yet to report: the group's)
-        if (tail_cells + cells > cap) break;
+        // (a group longer than a whole CU's mean load would hold up every launch it is part of: for those the cap is 8 % --
+        // c3 at 10 % of its size, 423 groups of which most are that long: 2 970 GCUPS under the 2.5 % cap, 3 680 under 8 %)
+        if (tail_cells + cells > ((double)gd.ncols > mean ? std::max(cap, (double)rg.cols * kGroupSeqs * 0.08) : cap) && c->opt_tail_cap > 0) break;
         tail_cells += cells;
         is_tail[g] = 1;
         rest -= gd.ncols;

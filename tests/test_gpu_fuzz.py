@@ -46,7 +46,7 @@ def draw_case(seed):
     opts = {}
     pool = [("resident", [0, 1]), ("dynamic", [0]), ("tail_mode", [1, 2]), ("f16", [0]), ("force_i32", [1]), ("wg_limit", [4, 64]),
             ("bnd_mib", [1]), ("alternate", [0]), ("split", [0]), ("rotate", [0]), ("lane_rows", [0]), ("score_mib", [1]), ("tail_frac", [10, 200]),
-            ("lane_room", [0, 1]), ("lane_acquire", [1]), ("max_waves", [1, 4, 8]), ("upload_piece_kib", [16, 64, 1024])]
+            ("lane_room", [0, 1]), ("lane_acquire", [1]), ("max_waves", [1, 4, 8]), ("upload_piece_kib", [16, 64, 1024]), ("tail_cap", [0, 5, 80])]
     for key, vals in pool:
         if rng.random() < 0.2:
             opts[key] = int(rng.choice(vals))

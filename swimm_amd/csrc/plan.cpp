@@ -380,7 +380,10 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> 
     // so the tail takes at most tail_cap per mille of the search's cells (pairs run to their longer member).  Measured
     // (profiles/r02_tail_fraction.txt): c3 at full size is best at 30 % / 2.5 % of the cells (8 180 GCUPS; 7 910 at 50 % /
     // 1.1 %, 7 750 at 20 % / 9 %), c3 at 30 % of its size at 2.5-7 % (6 170-6 190; 4 900 at 29 %, 2 300 at 93 %).
-    const double cap = c->opt_tail_cap > 0 ? (double)rg.cols * kGroupSeqs * (c->opt_tail_cap + 0.5) * 1e-3 : 1e300;
+    // (no cap for a database of fewer groups than CUs: the pipeline kernel could not even give every CU a group, the lane-systolic
+    // kernel spreads every alignment over a wave -- 1.2e7 residues: 2 250 GCUPS all through the lane kernel, 1 680 under the cap)
+    const bool capped = c->opt_tail_cap > 0 && n >= (uint32_t)c->num_cu;
+    const double cap = capped ? (double)rg.cols * kGroupSeqs * (c->opt_tail_cap + 0.5) * 1e-3 : 1e300;
     double tail_cells = 0;
     for (uint32_t g : order) {
         const GroupDesc &gd = c->groups[rg.g0 + g];
@@ -391,7 +394,7 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> 
         if (cells == 0) cells = 128.0 * gd.ncols;          // (a chunk whose true lengths the re-tile kernel has yet to report: the group's)
         // (a group longer than a whole CU's mean load would hold up every launch it is part of: for those the cap is 8 % --
         // c3 at 10 % of its size, 423 groups of which most are that long: 2 970 GCUPS under the 2.5 % cap, 3 680 under 8 %)
-        if (tail_cells + cells > ((double)gd.ncols > mean ? std::max(cap, (double)rg.cols * kGroupSeqs * 0.08) : cap) && c->opt_tail_cap > 0) break;
+        if (capped && tail_cells + cells > ((double)gd.ncols > mean ? std::max(cap, (double)rg.cols * kGroupSeqs * 0.08) : cap)) break;
         tail_cells += cells;
         is_tail[g] = 1;
         rest -= gd.ncols;

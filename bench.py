@@ -30,6 +30,7 @@ against it and a mismatch is a non-zero exit.
 """
 import argparse
 import glob
+import datetime
 import json
 import os
 import socket
@@ -234,7 +235,10 @@ def main():
         dist.init_process_group(backend="gloo")
         if not share:
             try:
-                rccl = dist.new_group(backend="nccl")
+                # (a rank whose RCCL set-up fails leaves the others inside this collective: they give up after a minute and
+                # everybody meets again in the gloo all_reduce below)
+                os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+                rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=60))
                 t = torch.ones(1, device="cuda")
                 dist.all_reduce(t, group=rccl)
                 torch.cuda.synchronize()

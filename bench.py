@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the SWIMM hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c5] [--scale S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--scale S]
 
---workload c2 (default; BASELINE.json configs[1], the configuration the metric is quoted on): one 375-residue query
-    (P07327-shaped, synthetic) against 1 000 004 synthetic proteins (~6e8 residues, log-normal lengths), BLOSUM62,
-    gap 10/2, top-20.  With N > 1 every rank holds its own 1M-sequence shard (seed differs per rank) of an
-    N-million-sequence database: WEAK scaling.
---workload c5 (BASELINE.json configs[4], north_star's multi-GPU case): the 20-query set against ONE Env-NR-shaped
-    database (35.5 M sequences / 7e9 residues at --scale 1; default 0.25 so that generating it stays within minutes),
-    PAM250, cut into 8 N slabs of equal padded size that are dealt statically to the N ranks
-    (sharding.assign_chunks): STRONG scaling, the total work does not depend on N.
+What one invocation measures (no --workload given):
+
+  top level   c2 (BASELINE.json configs[1], the configuration the metric is quoted on): one 375-residue query
+              (P07327-shaped, synthetic) against 1 000 004 synthetic proteins (~6e8 residues, log-normal lengths),
+              BLOSUM62, gap 10/2, top-20; K timed steps after W warm-up steps.  With N > 1 every rank holds its own
+              1M-sequence shard (seed differs per rank): WEAK scaling -- the same per-GPU work at every N, so that the
+              N = 1 point of a scaling run is the single-GPU bench line.
+  N = 1       `secondary`: the Env-NR-shaped configurations north_star's target sentence is written about, each with its
+              own parity sample against the reference, kernel name, `roofline` and `cpu_baseline`:
+                c4  the 5 478-residue query (Q9UKN1-shaped) x the 1.3e9-residue Env-NR subsample, BLOSUM62 10/2
+                c5  the 20-query set x the Env-NR-shaped database at scale 0.25 (1.75e9 residues), PAM250
+              (2 timed steps each after 1 warm-up step).
+  N > 1       `strong_scaling`: north_star's multi-GPU case, BASELINE.json configs[4] -- ONE Env-NR-shaped database
+              (35.5 M sequences / 7e9 residues), 20 queries, PAM250, cut into 8 N slabs of equal padded size that are
+              dealt statically to the N ranks (sharding.assign_chunks); per-rank kernel GCUPS and HBM fraction, which
+              path carried the top-20 lists, and the parity flags of every rank.  The total work does not depend on N.
+
+--workload X runs X alone as the top-level record (profiling runs, rehearsals); --scale applies to it.
 
 A "step" is one complete search of the resident database shard: DP kernels, promotion re-runs, device top-20; with
 N > 1 the ranks' top-20 lists are all-gathered (RCCL; 20 x 16 bytes per query and rank) and merged on the host --
@@ -23,14 +33,14 @@ relays rank 0's line.
 
 Prints ONE JSON line on rank 0: metric GCUPS = Q_real * D / t / 1e9 (swimm.c:163), `roofline` (dominant kernel,
 HIP-event timed inside the library on the streams the kernels run on), `valu_roofline` (the ceiling that binds this
-kernel, against both the guide's SIMD issue peak and the measured rate of its instruction class) and, at N = 1,
-`cpu_baseline` (the reference's own AVX2 path from oracle/_ref timed on the host cores).  The oracle is only ever
-the thing compared against, never the thing measured as `value`; every rank checks a sample of its own scores
-against it and a mismatch is a non-zero exit.
+kernel, against the guide's SIMD issue peak and its instruction class's 4-cycle rate) and, at N = 1, `cpu_baseline`
+(the reference's own AVX2 path from oracle/_ref timed on the host cores).  The oracle is only ever the thing compared
+against, never the thing measured as `value`; every rank checks a sample of its own scores against it and a mismatch
+is a non-zero exit.
 """
 import argparse
-import glob
 import datetime
+import glob
 import json
 import os
 import socket
@@ -49,19 +59,20 @@ METRIC = "GCUPS (whole node) + bit-exact top-r scores vs CPUsearch.c"   # BASELI
 QUERY_INDEX = 3          # P07327, 375 aa, in synth.QUERY_SET
 TOP_R = 20
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+NUM_CU, SHADER_HZ = 256, 2.4e9
 # VALU ceilings in wave64 instructions per second (256 CUs x 4 SIMDs x 2.4 GHz):
 #   the guide's issue peak -- a SIMD issues a wave64 VALU instruction over 2 cycles (157.3 TFLOPS fp32 vector);
-#   the instruction class of this kernel -- every VOP3P packed / 3-source op takes 4 cycles on gfx950, and measures
-#   4.40 with 4 waves per SIMD in isolation (tools/microbench/valu_rate, profiles/r01_valu_issue_rates.txt)
-VALU_PEAK_SIMD_ISSUE = 256 * 4 * 2.4e9 / 2 / 1e9
-VALU_PEAK_CLASS = 256 * 4 * 2.4e9 / 4 / 1e9
-VALU_MEASURED_CLASS = 256 * 4 * 2.4e9 / 4.40 / 1e9
+#   the instruction class of this kernel -- every VOP3P packed / 3-source op takes 4 cycles on gfx950
+#   (tools/microbench/valu_rate, profiles/r01_valu_issue_rates.txt: 4.2-4.5 measured in isolation, by occupancy)
+VALU_PEAK_SIMD_ISSUE = NUM_CU * 4 * SHADER_HZ / 2 / 1e9
+VALU_PEAK_CLASS = NUM_CU * 4 * SHADER_HZ / 4 / 1e9
 INSTR_PER_ROW, INSTR_PER_COLUMN = 8.5, 10          # model when no PMC profile matches: 7.5 packed-f16 ops + 1 v_perm per packed row; per-column overhead
+C4_SCALE = 1.3e9 / 6.99e9                          # the 1.3e9-residue Env-NR subsample of SURVEY 8d
+DEFAULT_SCALE = {"c2": 1.0, "c4": C4_SCALE, "c5": 0.25}
 
 
 def build_shard(seed: int, scale: float):
     """sorted lengths + recoded residues of one c2 shard, with planted homologs of the query"""
-    t0 = time.time()
     base_len = synth.lengths_lognormal(seed, max(256, int(1_000_000 * scale)), 600.0, 0.55, 30, 5000)
     queries = synth.make_queries(2)
     q_title, q_letters = queries[QUERY_INDEX]
@@ -83,9 +94,7 @@ def build_shard(seed: int, scale: float):
     for k, (_, seq) in enumerate(planted):
         p = pos_of[len(base_len) + k]
         codes[offs[p]:offs[p] + len(seq)] = host.recode(seq)
-    qa = host.recode(q_letters)
-    return {"lengths": lens_sorted, "codes": codes, "residues": total, "n": len(lens_sorted),
-            "query": qa, "gen_s": time.time() - t0}
+    return {"lengths": lens_sorted, "codes": codes, "residues": total, "n": len(lens_sorted), "query": host.recode(q_letters)}
 
 
 def host_cpus():
@@ -139,21 +148,19 @@ def sample_check(qa_list, lens, codes_of, sm, threads, gpu_scores_of, budget_s, 
     return ok, stride, len(idx), int(sub_lens.astype(np.int64).sum()), wt, kind
 
 
-def pmc_profile(workload, scale, plan, kernel, launches):
-    """PMC summary of exactly this configuration + launch plan, if one is committed under profiles/ (rocprofv3 --pmc
-    passes, tools/profile_bench.sh + tools/summarize_profile.py); None otherwise -- a number from another
-    configuration is not this run's traffic."""
-    best = None
+def pmc_profiles(workload, scale):
+    """the PMC summaries committed under profiles/ for this configuration (rocprofv3 --pmc passes, tools/profile_bench.sh
+    + tools/summarize_profile.py), latest round last"""
+    out = []
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json"))):
         try:
             d = json.load(open(fn))
         except Exception:
             continue
-        if (d.get("workload_key") == workload and abs(float(d.get("scale", -1)) - scale) < 1e-9 and d.get("plan") == plan and d.get("kernel") == kernel
-                and d.get("kernel_launches_per_search") == launches):
+        if d.get("workload_key") == workload and abs(float(d.get("scale", -1)) - scale) < 1e-6:
             d["file"] = os.path.relpath(fn, ROOT)
-            best = d
-    return best
+            out.append(d)
+    return out
 
 
 def spawn_ranks(args):
@@ -162,6 +169,9 @@ def spawn_ranks(args):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(args.gpus):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's
+        # buffer exchange between the ranks fails in hipIpcGetMemHandle.  The image exports it already: a launcher's
+        # own value wins, the default only covers an environment that lost it.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -185,127 +195,150 @@ def spawn_ranks(args):
     return rc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=("c2", "c5"), default="c2")
-    ap.add_argument("--scale", type=float, default=None, help="fraction of the configuration's database (default: c2 1.0, c5 0.25)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cold", action="store_true", help="skip the first-search-after-a-cold-upload measurement (profiling runs: only the resident search's launches in the trace)")
-    ap.add_argument("--rows-per-wave", type=int, default=0)
-    ap.add_argument("--max-waves", type=int, default=0)
-    ap.add_argument("--wgs-per-cu", type=int, default=0)
-    args = ap.parse_args()
-    if args.scale is None:
-        args.scale = 1.0 if args.workload == "c2" else 0.25
+class Env:
+    """this rank: its device, the process groups, the host threads it may use for the checker"""
+    rank = 0; local_rank = 0; world = 1
+    dist = None; rccl = None; rccl_ranks = 0; rccl_error = None
+    share = False; dev_index = 0; physical_gpus = 1
+    threads = 1; cores = 1; threads_all = 1
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(spawn_ranks(args))
-    # stdout carries the ONE JSON line and nothing else: whatever the libraries print there (gloo's connection notes, ...)
-    # goes to stderr from here on
-    json_out = os.fdopen(os.dup(1), "w")
-    sys.stdout.flush()
-    os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+def setup(args) -> Env:
     import torch
+    env = Env()
+    env.rank = int(os.environ.get("RANK", "0"))
+    env.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    env.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env.world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    share = os.environ.get("SWIMM_BENCH_SHARE_DEVICE") == "1"   # rehearsal only: every rank on GPU 0, gloo only
+    env.share = os.environ.get("SWIMM_BENCH_SHARE_DEVICE") == "1"   # rehearsal only: every rank on GPU 0, gloo only
     visible = torch.cuda.device_count()
-    if not share and world > 1 and visible < world:
-        # fewer visible devices than ranks (e.g. a launcher that gives every rank its own HIP_VISIBLE_DEVICES): take what is
-        # there; when ranks end up on one device the line says so
-        share = visible <= 1 and os.environ.get("HIP_VISIBLE_DEVICES") is None and os.environ.get("ROCR_VISIBLE_DEVICES") is None
-    dev_index = 0 if share else local_rank % max(visible, 1)
-    torch.cuda.set_device(dev_index)
-    dist = None
-    rccl = None
-    rccl_ranks = 0
-    if world > 1:
+    env.dev_index = 0 if env.share else env.local_rank % max(visible, 1)
+    torch.cuda.set_device(env.dev_index)
+    env.threads_all, env.cores = host_cpus()
+    env.threads = max(1, env.threads_all // env.world)
+    if env.world > 1:
         import torch.distributed as dist
+        env.dist = dist
         # control plane (barrier, max-over-ranks) on gloo; the only data exchange of the path -- the ranks' top-20
         # lists, once per step -- goes over RCCL
         dist.init_process_group(backend="gloo")
-        if not share:
+        # which physical devices do the ranks sit on?  (a launcher may give every rank its own HIP_VISIBLE_DEVICES, so
+        # the index says nothing: compare the devices' identities)
+        prop = torch.cuda.get_device_properties(env.dev_index)
+        ident = (socket.gethostname(), str(getattr(prop, "uuid", "")), getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1),
+                 getattr(prop, "pci_domain_id", -1))
+        idents = [None] * env.world
+        dist.all_gather_object(idents, ident)
+        env.physical_gpus = len(set(idents))
+        if env.physical_gpus < env.world and not env.share:
+            if env.rank == 0:
+                print(f"bench.py: {env.world} ranks on {env.physical_gpus} physical GPU(s); set SWIMM_BENCH_SHARE_DEVICE=1 to rehearse "
+                      f"on a shared device (the value is then not a multi-GPU figure)", file=sys.stderr)
+            raise SystemExit(3)
+        if not env.share:
+            err = None
             try:
                 # (a rank whose RCCL set-up fails leaves the others inside this collective: they give up after a minute and
-                # everybody meets again in the gloo all_reduce below)
+                # everybody meets again in the gloo exchange below)
                 os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
-                rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=60))
+                env.rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=60))
                 t = torch.ones(1, device="cuda")
-                dist.all_reduce(t, group=rccl)
+                dist.all_reduce(t, group=env.rccl)
                 torch.cuda.synchronize()
-                rccl_ranks = int(t.item())
-                assert rccl_ranks == world
-            except Exception as e:   # result path only: fall back to gloo, say so in the output
-                print(f"[rank {rank}] RCCL group unavailable ({e}); top-r lists go over gloo", file=sys.stderr)
-                rccl = None
-            ok = torch.tensor([1 if rccl is not None else 0], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank takes the same result path
-            if int(ok.item()) == 0:
-                rccl = None
-                rccl_ranks = 0
+                env.rccl_ranks = int(t.item())
+                if env.rccl_ranks != env.world:
+                    raise RuntimeError(f"RCCL all_reduce saw {env.rccl_ranks} of {env.world} ranks")
+            except Exception as e:   # result path only: fall back to gloo, and SAY so in the JSON line
+                err = f"rank {env.rank}: {type(e).__name__}: {e}"
+                print(f"[rank {env.rank}] RCCL group unavailable ({e}); top-r lists go over gloo", file=sys.stderr)
+            errs = [None] * env.world
+            dist.all_gather_object(errs, err)             # every rank takes the same result path
+            errs = [e for e in errs if e]
+            if errs:
+                env.rccl = None
+                env.rccl_ranks = 0
+                env.rccl_error = " | ".join(errs)[:2000]
+        else:
+            env.rccl_error = "not attempted: all ranks share one device (SWIMM_BENCH_SHARE_DEVICE=1)"
+    return env
 
-    threads_all, cores_all = host_cpus()
-    my_threads = max(1, threads_all // world)
-    searcher = hip_backend.HipSearcher(dev_index)
+
+def make_workload(env: Env, name: str, scale: float):
+    """the rank's shard of a configuration: queries, matrix, how to upload it, how to check it"""
+    w = {"name": name, "scale": scale, "chunks": None}
+    t0 = time.time()
+    if name == "c2":
+        w["sm"] = submat.table("blosum62")
+        shard = build_shard(2 + 1000 * env.rank, scale)
+        chunks = host.Chunks(shard["lengths"], shard["codes"], 128, 96 << 20)
+        w["chunks"] = chunks
+        w["qa_list"] = [shard["query"]]
+        w["a"], w["m"], w["disp"] = shard["query"], np.array([len(shard["query"])], np.uint16), np.array([0, len(shard["query"])], np.uint32)
+        w["my_lens"], w["my_n"], w["n_valid"], w["score_stride"] = shard["lengths"], shard["n"], shard["n"], chunks.vc * 128
+        w["my_residues"], w["my_padded"] = shard["residues"], chunks.vD
+        offs = np.concatenate([[0], np.cumsum(shard["lengths"].astype(np.int64))])
+        w["local_index"] = np.arange(shard["n"], dtype=np.int64)      # position of the rank's sequences in its score rows
+        w["codes_of"] = lambda i: shard["codes"] if i is None else shard["codes"][offs[i]:offs[i + 1]]
+        w["index_base"] = env.rank * (1 << 40)                         # ranks hold disjoint databases: make the merged indices distinct
+        w["text"] = "c2: 375-aa query x 1M synthetic proteins per GPU, BLOSUM62 g10 e2, top-20"
+        w["scaling"] = "weak"
+        w["upload_kind"] = "reference chunk layout"
+
+        def upload(searcher):
+            for ch in chunks.chunks:
+                searcher.add_chunk(ch["b"], ch["n"], ch["disp"], 128, ch["first_group"])
+    else:
+        db = workloads.SortedDb(name, scale)
+        w["sm"] = submat.table(db.matrix)
+        slabs = db.slabs(8 * env.world)
+        owner = sharding.assign_chunks([s[2] for s in slabs], env.world)
+        mine = [s for s, o in zip(slabs, owner) if o == env.rank]
+        w["a"], w["m"], w["disp"] = db.a, db.m, db.disp
+        w["qa_list"] = [db.a[db.disp[k]:db.disp[k + 1]] for k in range(len(db.m))]
+        slab_codes = [db.codes(s0, s1) for s0, s1, _ in mine]
+        local_index = np.concatenate([np.arange(s0, s1, dtype=np.int64) for s0, s1, _ in mine])
+        w["local_index"] = local_index
+        w["my_lens"] = db.lengths[local_index]
+        w["my_n"], w["n_valid"], w["score_stride"] = len(local_index), db.n, (db.n + 127) // 128 * 128
+        w["my_residues"], w["my_padded"] = int(w["my_lens"].astype(np.int64).sum()), sum(s[2] for s in mine)
+        w["codes_of"] = lambda i: np.concatenate(slab_codes) if i is None else db.codes(int(local_index[i]), int(local_index[i]) + 1)
+        w["index_base"] = 0                                            # one database: indices are global already
+        if name == "c4":
+            w["text"] = (f"c4: 5478-aa query x Env-NR-shaped database at scale {scale:.4f} ({db.n} sequences, {db.residues} residues), "
+                         f"BLOSUM62 g10 e2, top-20; {len(slabs)} slabs dealt statically to {env.world} rank(s)")
+        else:
+            w["text"] = (f"c5: 20-query set (144-5478 aa) x ONE Env-NR-shaped database at scale {scale} ({db.n} sequences, "
+                         f"{db.residues} residues), PAM250 g10 e2, top-20; {len(slabs)} slabs dealt statically to {env.world} rank(s)")
+        w["scaling"] = "strong"
+        w["upload_kind"] = ".seq slabs"
+
+        def upload(searcher):
+            for (s0, s1, _), codes in zip(mine, slab_codes):
+                searcher.add_sequences(db.lengths[s0:s1], codes, first_seq=s0)
+    w["upload"] = upload
+    w["datagen_s"] = time.time() - t0
+    return w
+
+
+def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: int, cpu_budget: float, want_cold: bool, want_cpu_baseline: bool):
+    """one configuration on this rank's GPU: upload, warm-up, the timed steps, parity against the CPU checker, the first
+    search after a cold upload.  -> (record (rank 0; None elsewhere), ok on every rank)"""
+    import torch
+    dist, world, rank = env.dist, env.world, env.rank
+    w = make_workload(env, name, scale)
+    searcher = hip_backend.HipSearcher(env.dev_index)
     for k, v in (("rows_per_wave", args.rows_per_wave), ("max_waves", args.max_waves), ("wgs_per_cu", args.wgs_per_cu)):
         if v:
             searcher.set_option(k, v)
     searcher.set_option("time_launches", 1)      # HIP events around every pipeline launch, on the stream it runs on
-
-    # ---- the rank's shard, resident in HBM ------------------------------------------------------------------
-    t_gen = time.time()
-    chunks = None
-    if args.workload == "c2":
-        sm = submat.table("blosum62")
-        shard = build_shard(2 + 1000 * rank, args.scale)
-        chunks = host.Chunks(shard["lengths"], shard["codes"], 128, 96 << 20)
-        qa_list = [shard["query"]]
-        a, m, disp = shard["query"], np.array([len(shard["query"])], np.uint16), np.array([0, len(shard["query"])], np.uint32)
-        my_lens, my_n, n_valid, score_stride = shard["lengths"], shard["n"], shard["n"], chunks.vc * 128
-        my_residues, my_padded = shard["residues"], chunks.vD
-        offs = np.concatenate([[0], np.cumsum(shard["lengths"].astype(np.int64))])
-        local_index = np.arange(my_n, dtype=np.int64)            # position of the rank's sequences in its score rows
-        codes_of = lambda i: shard["codes"] if i is None else shard["codes"][offs[i]:offs[i + 1]]   # noqa: E731
-        index_base = rank * (1 << 40)                            # ranks hold disjoint databases: make the merged indices distinct
-        workload_txt = "c2: 375-aa query x 1M synthetic proteins per GPU, BLOSUM62 g10 e2, top-20"
-
-        def upload():
-            for ch in chunks.chunks:
-                searcher.add_chunk(ch["b"], ch["n"], ch["disp"], 128, ch["first_group"])
-    else:
-        db = workloads.SortedDb("c5", args.scale)
-        sm = submat.table(db.matrix)
-        slabs = db.slabs(8 * world)
-        owner = sharding.assign_chunks([s[2] for s in slabs], world)
-        mine = [s for s, o in zip(slabs, owner) if o == rank]
-        a, m, disp = db.a, db.m, db.disp
-        qa_list = [a[disp[k]:disp[k + 1]] for k in range(len(m))]
-        slab_codes = [db.codes(s0, s1) for s0, s1, _ in mine]
-        local_index = np.concatenate([np.arange(s0, s1, dtype=np.int64) for s0, s1, _ in mine])
-        my_lens = db.lengths[local_index]
-        my_n, n_valid, score_stride = len(local_index), db.n, (db.n + 127) // 128 * 128
-        my_residues, my_padded = int(my_lens.astype(np.int64).sum()), sum(s[2] for s in mine)
-        codes_of = lambda i: np.concatenate(slab_codes) if i is None else db.codes(int(local_index[i]), int(local_index[i]) + 1)   # noqa: E731
-        index_base = 0                                           # one database: indices are global already
-        workload_txt = (f"c5: 20-query set (144-5478 aa) x ONE Env-NR-shaped database at scale {args.scale} ({db.n} sequences, "
-                        f"{db.residues} residues), PAM250 g10 e2, top-20; {len(slabs)} slabs dealt statically to {world} rank(s)")
-
-        def upload():
-            for (s0, s1, _), codes in zip(mine, slab_codes):
-                searcher.add_sequences(db.lengths[s0:s1], codes, first_seq=s0)
-    t_gen = time.time() - t_gen
-    searcher.set_queries(a, m, disp, sm, 10, 2)
+    sm, m = w["sm"], w["m"]
+    nq = len(m)
+    searcher.set_queries(w["a"], m, w["disp"], sm, 10, 2)
     t_up = time.time()
-    upload()
+    w["upload"](searcher)
     t_up = time.time() - t_up
 
     def barrier():
@@ -314,17 +347,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    nq = len(m)
-
     def exchange(ts, ti):
         """the path's only exchange step: every rank's top-20 per query -> merged listing (host merge, utils.c order)"""
         if dist is None:
             return ts, ti
-        mine_t = torch.from_numpy(np.concatenate([ts.astype(np.int64).ravel(), np.where(ti >= 0, ti + index_base, -1).ravel()]))
-        if rccl is not None:
+        mine_t = torch.from_numpy(np.concatenate([ts.astype(np.int64).ravel(), np.where(ti >= 0, ti + w["index_base"], -1).ravel()]))
+        if env.rccl is not None:
             mine_t = mine_t.cuda()
             allv = [torch.empty_like(mine_t) for _ in range(world)]
-            dist.all_gather(allv, mine_t, group=rccl)
+            dist.all_gather(allv, mine_t, group=env.rccl)
         else:
             allv = [torch.empty_like(mine_t) for _ in range(world)]
             dist.all_gather(allv, mine_t)
@@ -335,43 +366,56 @@ def main():
         return ms, mi
 
     def one_step():
-        ts, ti, wt = searcher.search_topr(TOP_R, n_valid)
+        ts, ti, wt = searcher.search_topr(TOP_R, w["n_valid"])
         ms, mi = exchange(ts, ti)
         return ms, mi, wt
 
-    for _ in range(args.warmup):
-        one_step()
+    n_searches = 0
+    for _ in range(warmup):
+        one_step(); n_searches += 1
     kernel_ms, wts, launch_ms = [], [], []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        top_s, top_i, wt = one_step()
+    for _ in range(steps):
+        top_s, top_i, wt = one_step(); n_searches += 1
         kernel_ms.append(searcher.last_stats()["kernel_ms"])
         launch_ms.append(searcher.last_launch_ms())
         wts.append(wt)
     barrier()
     elapsed = time.perf_counter() - t0
+    my_residues, my_padded, my_n = w["my_residues"], w["my_padded"], w["my_n"]
     total_residues = float(my_residues)
     k_ms_mean = float(np.mean(kernel_ms))
-    k_ms_max = k_ms_mean
-    if dist is not None:
-        tmax = torch.tensor([elapsed, k_ms_mean], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, k_ms_max = float(tmax[0].item()), float(tmax[1].item())
-        res = torch.tensor([my_residues], dtype=torch.float64)
-        dist.all_reduce(res, op=dist.ReduceOp.SUM)
-        total_residues = float(res.item())
     stats = searcher.last_stats()
     plans = [searcher.last_plan(k) for k in range(nq)]
     kernel_name = searcher.last_kernel_name(nq - 1)          # the longest query's kernel dominates the device time
+    q_real = int(m.astype(np.int64).sum())
+    # Algorithmic HBM bytes of one search of this rank's shard (w = 2, T_eff = rows per pass): per pass the
+    # tiled database bytes are read once (1/m B per cell of the whole query); between two passes the strip boundary (H
+    # and F, 2 B each, per sequence and column = 4x the tiled residue bytes) is written once and read once; 8 B per
+    # sequence and query for the scores.  For c2 (one query, `passes` launches of one kernel) divided by the launches
+    # this is the per-launch figure of DESIGN.md; for a query batch it is the sum over the queries.
+    alg_bytes = sum(float(my_padded) * (p["passes"] + 8.0 * (p["passes"] - 1)) + 8.0 * my_n for p in plans)
+    my_kernel_gcups = q_real * float(my_residues) / (k_ms_mean * 1e-3) / 1e9
+    my_hbm_frac = alg_bytes / (k_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS
+    per_rank = [(my_kernel_gcups, my_hbm_frac)]
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0].item())
+        res = torch.tensor([my_residues], dtype=torch.float64)
+        dist.all_reduce(res, op=dist.ReduceOp.SUM)
+        total_residues = float(res.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, (my_kernel_gcups, my_hbm_frac))
 
     # ---- parity: every rank checks a sample of its own scores, and the merged listing, against the CPU checker ----
-    q_real = int(m.astype(np.int64).sum())
-    full = np.zeros((nq, score_stride), dtype=np.int32)
-    searcher.search(score_stride, out=full)
+    full = np.zeros((nq, w["score_stride"]), dtype=np.int32)
+    searcher.search(w["score_stride"], out=full); n_searches += 1
+    local_index = w["local_index"]
     mine_scores = full[:, local_index]
-    budget = 25.0 if (world == 1 and not args.no_cpu_baseline) else 6.0
-    ok, stride, n_s, res_s, cpu_s, kind = sample_check(qa_list, my_lens, codes_of, sm, my_threads, lambda idx: mine_scores[:, idx], budget, my_n)
+    del full
+    ok, stride, n_s, res_s, cpu_s, kind = sample_check(w["qa_list"], w["my_lens"], w["codes_of"], sm, env.threads, lambda idx: mine_scores[:, idx], cpu_budget, my_n)
     # the merged top-20 of the timed path (device top-r + exchange) against a host selection over the ranks' full vectors
     hs = np.zeros((nq, TOP_R), np.int32); hi = np.zeros((nq, TOP_R), np.int64)
     for k in range(nq):
@@ -379,6 +423,7 @@ def main():
         hs[k], hi[k] = s_, np.where(i_ >= 0, local_index[np.maximum(i_, 0)], -1)
     ms2, mi2 = exchange(hs, hi)
     ok_top = bool(np.array_equal(ms2, top_s) and np.array_equal(mi2, top_i))
+    del mine_scores
     flags = torch.tensor([1 if ok else 0, 1 if ok_top else 0], dtype=torch.int32)
     if dist is not None:
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)
@@ -386,109 +431,212 @@ def main():
 
     # ---- first search after a cold upload (the reference's workTime brackets the transfers, MICsearch.c:51,350) ----
     cold_s = float("nan")
-    if not args.no_cold:
+    if want_cold:
         searcher.clear_db()
         searcher.set_option("lazy_upload", 1)        # chunks stream in while the search runs (what swimm_hip_search_chunks does)
         barrier()
         t0 = time.perf_counter()
-        upload()
-        exchange(*searcher.search_topr(TOP_R, n_valid)[:2])
+        w["upload"](searcher)
+        exchange(*searcher.search_topr(TOP_R, w["n_valid"])[:2])
         barrier()
         cold_s = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([cold_s], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        cold_s = float(tmax.item())
+        if dist is not None:
+            tmax = torch.tensor([cold_s], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            cold_s = float(tmax.item())
 
+    rec = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        gcups = q_real * total_residues * args.steps / elapsed / 1e9
+        ms_per_step = elapsed / steps * 1e3
+        gcups = q_real * total_residues * steps / elapsed / 1e9
         launches = max(1, stats["launches"])
-        # Algorithmic HBM bytes of one search of this rank's shard (w = 2, T_eff = rows per pass): per pass
-        # the tiled database bytes are read once (1/m B per cell of the whole query); between two passes the strip
-        # boundary (H and F, 2 B each, per sequence and column = 4x the tiled residue bytes) is written once and read
-        # once; 8 B per sequence and query for the scores.  For c2 (one query, `passes` launches of one kernel) divided
-        # by the launches this is the per-launch figure of DESIGN.md; for a query batch it is the sum over the queries.
-        alg_bytes = sum(float(my_padded) * (p["passes"] + 8.0 * (p["passes"] - 1)) + 8.0 * my_n for p in plans)
         # The dominant kernel's launches: the library brackets every pipeline launch with HIP events on the stream it is
         # launched on and reports their sum and number (two launches that share the chip on two streams each count with
         # their own, longer, duration -- exactly what a kernel trace lists per dispatch).
-        pipe_launches = max(1, int(round(np.mean([n for _, n in launch_ms]))))
-        per_launch_ms = max(float(np.mean([ms_ / max(n, 1) for ms_, n in launch_ms])), 1e-6)   # (a shard so small that every group runs on the lane-systolic kernel has no pipeline launch)
+        pipe_launches = int(round(np.mean([n for _, n in launch_ms])))
         single_kernel = nq == 1                                    # one query = one kernel instantiation: per-launch figures are meaningful
-        achieved = (alg_bytes / pipe_launches) / (per_launch_ms * 1e-3) / 1e9 if single_kernel else alg_bytes / (k_ms_mean * 1e-3) / 1e9
         plan_key = {"rows_per_wave": plans[-1]["rows_per_wave"], "waves": plans[-1]["waves"], "passes": plans[-1]["passes"]}
-        prof = pmc_profile(args.workload, args.scale, plan_key, kernel_name, pipe_launches) if (world == 1 and single_kernel) else None
-        traffic = prof["hbm_bytes_per_launch"] if prof else None
+        profs = pmc_profiles(name, scale) if world == 1 else []
         cells_real = q_real * float(my_residues)
         kernel_gcups = cells_real / (k_ms_mean * 1e-3) / 1e9
-        cells_padded = float(stats["cells"])
-        if prof and prof.get("sq_insts_valu_per_launch"):
-            n_instr = float(prof["sq_insts_valu_per_launch"]) * pipe_launches
-            instr_src = f"SQ_INSTS_VALU of {prof['file']}"
+        if pipe_launches < 1:
+            # a shard so small that every group went through the lane-systolic kernel: the pipeline kernel never ran, and a
+            # per-launch figure of a kernel that did not run would be fiction
+            roofline = None
+            roofline_note = ("no pipeline-kernel launch in this search: every group of the shard was aligned by sw_lane_kernel (lane-systolic, one wave per "
+                             "alignment; DESIGN.md 3.2), whose launches the library does not bracket one by one; device time of the search "
+                             f"{k_ms_mean:.3f} ms, algorithmic bytes {alg_bytes:.0f}")
         else:
+            per_launch_ms = float(np.mean([ms_ / max(n, 1) for ms_, n in launch_ms]))
+            achieved = (alg_bytes / pipe_launches) / (per_launch_ms * 1e-3) / 1e9 if single_kernel else alg_bytes / (k_ms_mean * 1e-3) / 1e9
+            prof = None
+            for d in profs:          # a number from another launch plan is not this run's traffic
+                if single_kernel and d.get("plan") == plan_key and d.get("kernel") == kernel_name and d.get("kernel_launches_per_search") == pipe_launches:
+                    prof = d
+            roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+                        "traffic_source": (prof["file"] if prof else "none: no PMC profile of this workload, scale and launch plan is committed (profiles/*_pmc_traffic*.json)"),
+                        "kernel": kernel_name, "kernel_ms": round(per_launch_ms, 4), "kernel_launches_per_search": pipe_launches,
+                        "device_ms_per_search": round(k_ms_mean, 4), "launches_per_search": launches,
+                        "achieved_chip_GBps": round(alg_bytes / (k_ms_mean * 1e-3) / 1e9, 3),
+                        "alg_bytes_per_search": alg_bytes, "alg_bytes_per_launch": alg_bytes / pipe_launches if single_kernel else None,
+                        "note": ("VALU-bound kernel (see valu_roofline); HBM carries the database residues once per pass and the strip boundary between passes; "
+                                 "achieved = alg_bytes_per_launch / kernel_ms (kernel_ms = average duration of the kernel's launches by HIP events on their own streams; "
+                                 "a query of three or more short passes runs two launches side by side on two streams, each at about half the chip: achieved_chip_GBps is bytes per search / device time)"
+                                 if single_kernel else "query batch: several kernel instantiations; achieved = algorithmic bytes per search / device time of the search")}
+            if prof and prof.get("lds_idx_active_per_launch") and prof.get("kernel_avg_ns"):
+                # the LDS side of the same profile (north_star: bank conflicts against the LDS pipe's busy cycles)
+                cyc = float(prof["kernel_avg_ns"]) * 1e-9 * SHADER_HZ * NUM_CU
+                roofline["lds"] = {"bank_conflict_frac": round(float(prof["lds_bank_conflict_per_launch"]) / float(prof["lds_idx_active_per_launch"]), 4),
+                                   "busy_frac": round(float(prof["lds_idx_active_per_launch"]) / cyc, 4),
+                                   "source": f"SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, SQ_LDS_IDX_ACTIVE / ({NUM_CU} CUs x kernel cycles) of {prof['file']} (a committed profile of this plan, not this run)"}
+            roofline_note = None
+        # VALU instructions: from a committed SQ_INSTS_VALU summary of this configuration -- per launch when the plan and
+        # kernel are this run's (one query), per search for a query batch -- else from the 8.5-per-row model
+        n_instr, instr_src = None, None
+        for d in profs:
+            if single_kernel and pipe_launches >= 1 and d.get("plan") == plan_key and d.get("kernel") == kernel_name and d.get("sq_insts_valu_per_launch"):
+                n_instr = float(d["sq_insts_valu_per_launch"]) * pipe_launches
+                instr_src = f"SQ_INSTS_VALU per launch of {d['file']} (a committed profile of this plan and kernel, not this run) x {pipe_launches} launches"
+            elif not single_kernel and d.get("sq_insts_valu_per_search") and d.get("plans") == plans:
+                n_instr = float(d["sq_insts_valu_per_search"])
+                instr_src = f"SQ_INSTS_VALU per search, all kernels, of {d['file']} (a committed profile of this configuration with the same launch plans, not this run)"
+        if n_instr is None:
             # wave-columns of query p = padded columns x waves x passes; each costs T x 8.5 + 10 instructions
             n_instr = sum(float(my_padded) / 128 * p["waves"] * p["passes"] * (p["rows_per_wave"] * INSTR_PER_ROW + INSTR_PER_COLUMN) for p in plans)
             instr_src = "model: 8.5 VALU instructions per packed row + 10 per column (no PMC profile of this configuration and plan under profiles/)"
         ginstr = n_instr / (k_ms_mean * 1e-3) / 1e9
-        out = {
-            "metric": METRIC, "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak" if args.workload == "c2" else "strong",
-            "vs_baseline": None, "dtype": "f16 (exact integers < 2048) -> int16 -> int32", "data": "synthetic",
-            "config": {"workload": workload_txt, "query_residues": q_real, "queries": nq,
+        rec = {
+            "value": round(gcups, 2), "unit": "GCUPS", "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
+            "scaling": w["scaling"],
+            "config": {"workload": w["text"], "query_residues": q_real, "queries": nq,
                        "db_sequences_rank0": my_n, "db_residues_rank0": my_residues, "db_residues_total": int(total_residues),
-                       "parallelism": f"db-shard x{world}", "plan": plans[-1], "scale": args.scale,
-                       "topr_exchange": "none" if world == 1 else ("rccl all_gather" if rccl is not None else "gloo all_gather"),
-                       "rccl_ranks": rccl_ranks},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_source": (prof["file"] if prof else "none: no PMC profile of this workload, scale and launch plan is committed (profiles/*_pmc_traffic*.json)"),
-                         "kernel": kernel_name, "kernel_ms": round(per_launch_ms, 4), "kernel_launches_per_search": pipe_launches,
-                         "device_ms_per_search": round(k_ms_mean, 4), "launches_per_search": launches,
-                         "achieved_chip_GBps": round(alg_bytes / (k_ms_mean * 1e-3) / 1e9, 3),
-                         "alg_bytes_per_search": alg_bytes, "alg_bytes_per_launch": alg_bytes / pipe_launches if single_kernel else None,
-                         "note": ("VALU-bound kernel (see valu_roofline); HBM carries the database residues once per pass and the strip boundary between passes; "
-                                  "achieved = alg_bytes_per_launch / kernel_ms (kernel_ms = average duration of the kernel's launches by HIP events on their own streams; "
-                                  "a query of three or more passes runs two launches side by side on two streams, each at about half the chip: achieved_chip_GBps is bytes per search / device time)"
-                                  if single_kernel else "query batch: several kernel instantiations; achieved = algorithmic bytes per search / device time of the search")},
+                       "parallelism": f"db-shard x{world}", "plan": plans[-1], "scale": scale,
+                       "topr_exchange": "none" if world == 1 else ("rccl all_gather" if env.rccl is not None else "gloo all_gather"),
+                       "rccl_ranks": env.rccl_ranks},
+            "roofline": roofline,
             "valu_roofline": {"achieved": round(ginstr, 1), "unit": "G wave64-instr/s", "instructions": instr_src,
                               "peak": round(VALU_PEAK_SIMD_ISSUE, 1), "frac": round(ginstr / VALU_PEAK_SIMD_ISSUE, 4),
                               "peak_source": "MI355X_MICROARCH.md: 4 SIMDs per CU, one wave64 VALU instruction issued over 2 cycles",
                               "class_peak": round(VALU_PEAK_CLASS, 1), "class_frac": round(ginstr / VALU_PEAK_CLASS, 4),
-                              "class_measured": round(VALU_MEASURED_CLASS, 1), "class_measured_frac": round(ginstr / VALU_MEASURED_CLASS, 4),
-                              "class_source": "VOP3P packed / 3-source ops issue over 4 cycles on gfx950; 4.40 measured in isolation with 4 waves per SIMD (profiles/r01_valu_issue_rates.txt)",
-                              "kernel_only_gcups": round(kernel_gcups, 2), "padded_cells": cells_padded},
+                              "class_source": ("VOP3P packed / 3-source ops issue over 4 cycles on gfx950 (profiles/r01_valu_issue_rates.txt); SQ_INSTS_VALU also counts the "
+                                               "few 2-cycle scalar-operand ops of a column's overhead, so class_frac is a slight over-estimate of the packed pipe's use"),
+                              "kernel_only_gcups": round(kernel_gcups, 2), "padded_cells": float(stats["cells"])},
             "search_call_ms": round(float(np.mean(wts)) * 1e3, 4),
-            "value_incl_h2d": None if args.no_cold else round(q_real * total_residues / cold_s / 1e9, 2),
-            "value_incl_h2d_note": f"first search after a cold upload of the shard (pageable host memory, {'reference chunk layout' if args.workload == 'c2' else '.seq slabs'}; chunk k+1 copied and tiled while chunk k is aligned), {cold_s * 1e3:.1f} ms",
-            "h2d_upload_s": round(t_up, 3), "datagen_s": round(t_gen, 2),
+            "value_incl_h2d": round(q_real * total_residues / cold_s / 1e9, 2) if want_cold else None,
+            "value_incl_h2d_note": (f"first search after a cold upload of the shard (pageable host memory, {w['upload_kind']}; chunk k+1 copied and tiled while chunk k is aligned), {cold_s * 1e3:.1f} ms"
+                                    if want_cold else None),
+            "h2d_upload_s": round(t_up, 3), "datagen_s": round(w["datagen_s"], 2), "searches_in_run": n_searches + (1 if want_cold else 0),
+            "plans": plans if nq > 1 else None,
             "top1": [int(top_s[0][0]), int(top_i[0][0])],
             "bit_exact_vs_reference": all_ok, "merged_top20_matches_full_vectors": all_top_ok,
             "parity_sample": f"every rank: every {stride}th sequence of its shard x all queries vs the CPU {kind} ({n_s} sequences, {res_s} residues on rank 0)",
         }
-        if share:
-            out["shared_device"] = True
-            out["note"] = "REHEARSAL: all ranks share GPU 0 (SWIMM_BENCH_SHARE_DEVICE=1); the value is not a multi-GPU figure"
+        if roofline_note:
+            rec["roofline_note"] = roofline_note
         if world > 1:
-            out["per_rank_kernel_gcups_min"] = round(q_real * float(my_residues) / (k_ms_max * 1e-3) / 1e9, 2)
-        if world == 1 and not args.no_cpu_baseline:
+            rec["per_rank_kernel_gcups"] = [round(x[0], 2) for x in per_rank]
+            rec["per_rank_kernel_gcups_min"] = round(min(x[0] for x in per_rank), 2)
+            rec["per_rank_kernel_gcups_max"] = round(max(x[0] for x in per_rank), 2)
+            rec["per_rank_hbm_frac"] = [round(x[1], 5) for x in per_rank]
+        if world == 1 and want_cpu_baseline:
             try:
                 model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
             except Exception:
                 model = "unknown"
-            out["cpu_baseline"] = {"value": round(q_real * res_s / cpu_s / 1e9, 2), "unit": "GCUPS", "cores": cores_all, "threads": my_threads,
+            rec["cpu_baseline"] = {"value": round(q_real * res_s / cpu_s / 1e9, 2), "unit": "GCUPS", "cores": env.cores, "threads": env.threads,
                                    "kind": kind, "cpu_model": model, "matches_gpu": ok,
-                                   "sample": f"{args.workload} shard, every {stride}th sequence ({n_s} sequences, {res_s} residues), {nq} quer{'y' if nq == 1 else 'ies'}, {cpu_s:.2f} s"}
-        print(json.dumps(out), file=json_out, flush=True)
+                                   "sample": f"{name} shard, every {stride}th sequence ({n_s} sequences, {res_s} residues), {nq} quer{'y' if nq == 1 else 'ies'}, {cpu_s:.2f} s"}
     searcher.close()
-    if chunks is not None:
-        chunks.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if w["chunks"] is not None:
+        w["chunks"].close()
     if not (all_ok and all_top_ok):
-        raise SystemExit(f"[rank {rank}] GPU scores differ from the CPU checker (sample ok: {all_ok}, merged top-20 ok: {all_top_ok})")
+        print(f"[rank {rank}] {name}: GPU scores differ from the CPU checker (sample ok: {all_ok}, merged top-20 ok: {all_top_ok})", file=sys.stderr)
+    return rec, all_ok and all_top_ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=("c2", "c4", "c5"), default=None,
+                    help="run this configuration alone (default: c2 at the top level + the secondary / strong-scaling records)")
+    ap.add_argument("--scale", type=float, default=None, help="fraction of the configuration's database (default: c2 1.0, c4 0.186, c5 0.25); with --workload")
+    ap.add_argument("--strong-scale", type=float, default=1.0, help="scale of the c5 database of the strong_scaling record at N > 1")
+    ap.add_argument("--secondary-steps", type=int, default=2)
+    ap.add_argument("--secondary-scale", type=float, default=1.0, help="multiplies the default scales of the secondary records (tests: small databases)")
+    ap.add_argument("--no-secondary", action="store_true", help="top-level record only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the first-search-after-a-cold-upload measurement (profiling runs: only the resident search's launches in the trace)")
+    ap.add_argument("--rows-per-wave", type=int, default=0)
+    ap.add_argument("--max-waves", type=int, default=0)
+    ap.add_argument("--wgs-per-cu", type=int, default=0)
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+    # stdout carries the ONE JSON line and nothing else: whatever the libraries print there (gloo's connection notes, ...)
+    # goes to stderr from here on
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    env = setup(args)
+    world = env.world
+
+    primary = args.workload or "c2"
+    scale = args.scale if (args.scale is not None and args.workload) else DEFAULT_SCALE[primary]
+    if args.scale is not None and not args.workload:
+        scale = args.scale                  # (--scale without --workload: a smaller c2, for rehearsals)
+    baseline = world == 1 and not args.no_cpu_baseline
+    rec, ok = run_workload(env, args, primary, scale, args.steps, args.warmup, 25.0 if baseline else 6.0, not args.no_cold, baseline)
+    all_ok = ok
+    extra = {}
+    if not args.workload and not args.no_secondary:
+        if world == 1:
+            secondary = []
+            for name in ("c4", "c5"):
+                r2, ok2 = run_workload(env, args, name, DEFAULT_SCALE[name] * args.secondary_scale, args.secondary_steps, 1, 10.0, not args.no_cold, baseline)
+                all_ok = all_ok and ok2
+                r2["workload"] = name
+                secondary.append(r2)
+            extra["secondary"] = secondary
+        else:
+            r2, ok2 = run_workload(env, args, "c5", args.strong_scale, args.secondary_steps, 1, 6.0, False, False)
+            all_ok = all_ok and ok2
+            if env.rank == 0:
+                extra["strong_scaling"] = {
+                    "workload": r2["config"]["workload"], "scale": args.strong_scale, "value": r2["value"], "unit": "GCUPS", "n_gpus": world,
+                    "steps": r2["steps"], "warmup": r2["warmup"], "ms_per_step": r2["ms_per_step"],
+                    "per_rank_kernel_gcups_min": r2["per_rank_kernel_gcups_min"], "per_rank_kernel_gcups_max": r2["per_rank_kernel_gcups_max"],
+                    "per_rank_kernel_gcups": r2["per_rank_kernel_gcups"],
+                    "hbm_frac": round(float(np.mean(r2["per_rank_hbm_frac"])), 5), "per_rank_hbm_frac": r2["per_rank_hbm_frac"],
+                    "hbm_frac_note": "per rank: algorithmic HBM bytes of its shard's search (SURVEY 8d: database bytes once per pass + the strip boundary between passes) / its device time / 8 TB/s",
+                    "rccl_ranks": env.rccl_ranks, "topr_exchange": r2["config"]["topr_exchange"],
+                    "bit_exact": r2["bit_exact_vs_reference"] and r2["merged_top20_matches_full_vectors"], "parity_sample": r2["parity_sample"],
+                    "plans": r2["plans"], "db_residues_total": r2["config"]["db_residues_total"], "datagen_s": r2["datagen_s"], "h2d_upload_s": r2["h2d_upload_s"],
+                }
+    if env.rank == 0:
+        out = {"metric": METRIC, "value": rec["value"], "unit": "GCUPS", "n_gpus": world, "steps": rec["steps"], "warmup": rec["warmup"],
+               "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"], "vs_baseline": None,
+               "dtype": "f16 (exact integers < 2048) -> int16 -> int32", "data": "synthetic"}
+        for k, v in rec.items():
+            if k not in out:
+                out[k] = v
+        out.update(extra)
+        if world > 1:
+            out["physical_gpus"] = env.physical_gpus
+            if env.rccl_error:
+                out["rccl_error"] = env.rccl_error
+        if env.share:
+            out["shared_device"] = True
+            out["note"] = "REHEARSAL: all ranks share GPU 0 (SWIMM_BENCH_SHARE_DEVICE=1); the value is not a multi-GPU figure"
+        print(json.dumps(out), file=json_out, flush=True)
+    if env.dist is not None:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
+    if not all_ok:
+        raise SystemExit(f"[rank {env.rank}] GPU scores differ from the CPU checker")
 
 
 if __name__ == "__main__":

@@ -131,9 +131,11 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    (default 25; 0 = no cap)
  *   "dynamic"        1 = default: workgroups pull groups from a global queue; 0 = static longest-first partition
  *   "lane_rows"      1 = default: one-pass lane-systolic launches of short queries use 2 / 4 query rows per lane; 0 = always 8
- *   "resident"       0 = default: one launch per pass of a multi-pass query ("split", "bnd_mib" apply); 1 = ONE launch, each
- *                    workgroup takes a group through all its passes back to back, the strip boundary in scratch only it
- *                    touches (no launch boundary; measured equal to the default within 1 %)
+ *   "resident"       group-resident batch launches (ONE launch per launch shape for all the queries that share it: each workgroup
+ *                    takes a (group, query) item through all its passes back to back, the strip boundary in scratch only it
+ *                    touches; no launch boundary).  -1 = default: formed when the call has two or more
+ *                    queries (or streams its database in) and the database is small beside the chip; 0 = never: one launch
+ *                    per pass of every query ("split", "bnd_mib" apply); 1 = always, every query joins
  *   "lane_room"      -1 = default: launch shapes leave a lane-systolic wave its registers when the database has a long-sequence
  *                    tail; 0 = never; 1 = always
  *   "rotate"         1 = default: when no group-resident batch is formed, eight or more one-pass queries run whole on three

@@ -827,6 +827,13 @@ int SearchRun::issue()
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_b, 0));
         HIP_TRY(hipEventRecord(c->ev_a, c->stream2));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_a, 0));
+        // (a chain-bound search rotates its tail launches over further streams, range after range: a query's tail kernel
+        // of an EARLY range may sit on one of them while ev_query[2q + 1] only marks the last range's -- the promotion
+        // ladder must not scan a score row a lane kernel is still writing)
+        for (int i = 0; i + 1 < tail_lanes; ++i) {
+            HIP_TRY(hipEventRecord(c->ev_tail_t[i], c->stream_t[i]));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail_t[i], 0));
+        }
         for (uint32_t q = 0; q < qn; ++q) HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
         c->up->finish(false);
         if (sync_lengths(c)) return 1;             // the promotion re-runs stop every alignment at its true length

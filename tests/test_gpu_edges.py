@@ -120,6 +120,20 @@ def test_every_strip_height_vs_oracle(T):
     run_case(seqs, queries, opts={"rows_per_wave": T, "waves": 4, "resident": 1})      # the group-resident instantiation of every height
 
 
+def test_streamed_ranges_rotating_tail_launches_then_promotion():
+    """A database that streams in as several ranges, small beside one extreme sequence (so the search is chain-bound and
+    the tail launches of consecutive queries rotate over three streams), with scores >= 2048 on that sequence: the
+    promotion ladder of a query must wait for the tail kernel of the FIRST range, whichever stream it ran on."""
+    rng = np.random.default_rng(414)
+    queries = [np.concatenate([np.full(230, CODE["W"], np.int8), rnd(rng, int(n))]) for n in (300, 340, 380, 420, 460, 500)]
+    long_seq = np.concatenate([rnd(rng, 9000)] + [np.concatenate([q, rnd(rng, 2500)]) for q in queries] + [rnd(rng, 3000)])
+    seqs = [rnd(rng, int(n)) for n in rng.integers(40, 260, 2600)] + [long_seq]
+    opts = {"lazy_upload": 1, "resident": 0, "upload_piece_kib": 16}
+    want, stats = run_case(seqs, queries, opts=opts, max_chunk=60000)
+    assert (want[:, -1] >= 2048).all()            # every query leaves the binary16 range on the extreme sequence
+    run_case(seqs, queries, opts=dict(opts, f16=0), max_chunk=60000)
+
+
 def test_mass_promotion():
     """a family of 66 000 near-copies of the query: every alignment leaves the binary16 range (>= 2048), more than
     any fixed-size list would hold; plus 40 W-runs that also leave int16.  All of them come back exact."""

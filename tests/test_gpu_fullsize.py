@@ -76,8 +76,8 @@ def test_bench_line_contract():
     import subprocess
     import sys
     from conftest import ROOT
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--scale", "0.03"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--scale", "0.03", "--secondary-scale", "0.02"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -93,3 +93,11 @@ def test_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["matches_gpu"] is True
+    assert d["roofline"]["frac"] <= 1.0 and d["bit_exact_vs_reference"] is True
+    # the Env-NR-shaped configurations ride on the same line, each with its own parity sample, roofline and CPU baseline
+    assert [r["workload"] for r in d["secondary"]] == ["c4", "c5"]
+    for r in d["secondary"]:
+        assert r["bit_exact_vs_reference"] is True and r["merged_top20_matches_full_vectors"] is True and r["value"] > 100
+        assert r["cpu_baseline"]["matches_gpu"] is True and r["cpu_baseline"]["kind"] in ("reference", "port")
+        assert r["roofline"] is None and "roofline_note" in r or (0 < r["roofline"]["frac"] <= 1.0 and "sw_" in r["roofline"]["kernel"])
+    assert d["secondary"][0]["config"]["queries"] == 1 and d["secondary"][1]["config"]["queries"] == 20

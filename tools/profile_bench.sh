@@ -7,7 +7,7 @@ TAG=${1:-r01}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-cold $*"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-cold --no-secondary $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py $ARGS > $OUT/kt.log 2>&1
 echo "kt rc=$?"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc1 -o pmc -- python3 bench.py $ARGS > $OUT/pmc1.log 2>&1

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses gpurun_out/prof_<tag>/ (written by tools/profile_bench.sh) into the files under profiles/.
 
-usage: python tools/summarize_profile.py <tag> [round-prefix, default r02] [label, default c2]
+usage: python tools/summarize_profile.py <tag> [round-prefix, default r03] [label, default c2] [kernel substring: summarise this kernel instead of the one with the most time]
   profiles/<rnd>_<label>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied)
   profiles/<rnd>_<label>_pmc_summary.csv    per-counter mean per launch of the dominant kernel
   profiles/<rnd>_pmc_traffic_<label>.json   HBM bytes per launch with the gfx950 corrections
@@ -24,7 +24,7 @@ def find(base, pat):
 
 def main():
     tag = sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
     label = sys.argv[3] if len(sys.argv) > 3 else "c2"
     base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = os.path.join(ROOT, "profiles")
@@ -34,15 +34,21 @@ def main():
         sys.exit(f"no kernel_stats.csv under {base}/kt")
     rows = list(csv.DictReader(open(stats[0])))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    want = sys.argv[4] if len(sys.argv) > 4 else None
+    if want:
+        rows = [r for r in rows if want in r["Name"]] + [r for r in rows if want not in r["Name"]]
     dominant = rows[0]["Name"]
     with open(os.path.join(out, f"{rnd}_{label}_kernel_stats.csv"), "w") as f:
         f.write(open(stats[0]).read())
 
     per = defaultdict(lambda: defaultdict(float))   # counter -> dispatch id -> value (summed over XCD rows)
+    per_dp = defaultdict(float)                     # counter -> sum over every DP kernel dispatch (pipeline + lane-systolic) of the run
     dispatch = None
     for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
         for fn in find(os.path.join(base, p), "*counter_collection.csv"):
             for r in csv.DictReader(open(fn)):
+                if "sw_pipe_kernel" in r["Kernel_Name"] or "sw_lane_kernel" in r["Kernel_Name"]:
+                    per_dp[r["Counter_Name"]] += float(r["Counter_Value"])
                 if r["Kernel_Name"] != dominant:
                     continue
                 per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
@@ -58,7 +64,7 @@ def main():
             f.write(f"{c},{len(v)},{sum(v) / len(v)}\n")
 
     def mean(c):
-        v = list(per[c].values())
+        v = list(per[c].values()) if c in per else []
         return sum(v) / len(v) if v else None
 
     # the configuration and launch plan the profiled command ran with: from its own JSON line (kt.log)
@@ -77,6 +83,12 @@ def main():
         traffic = {
             "workload_key": (cfg.get("workload", "c2").split(":")[0]), "scale": cfg.get("scale", 1.0), "plan": cfg.get("plan"),
             "sq_insts_valu_per_launch": mean("SQ_INSTS_VALU"),
+            # a query batch runs several kernel instantiations: all DP kernels' instructions of the run / its searches
+            "plans": line.get("plans"),
+            "sq_insts_valu_per_search": (per_dp["SQ_INSTS_VALU"] / line["searches_in_run"]) if line.get("searches_in_run") and per_dp.get("SQ_INSTS_VALU") else None,
+            "lds_bank_conflict_per_launch": mean("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_per_launch": mean("SQ_LDS_IDX_ACTIVE"),
+            "sq_wave_cycles_per_launch": mean("SQ_WAVE_CYCLES"), "sq_busy_cycles_per_launch": mean("SQ_BUSY_CYCLES"),
+            "sq_wait_inst_any_per_launch": mean("SQ_WAIT_INST_ANY"), "sq_active_inst_valu_per_launch": mean("SQ_ACTIVE_INST_VALU"),
             "kernel_launches_per_search": (line.get("roofline") or {}).get("kernel_launches_per_search"),
             "kernel_avg_ns": float(rows[0]["AverageNs"]), "kernel_calls": int(rows[0]["Calls"]),
             "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE, separate passes (profiles/{rnd}_{label}_pmc_summary.csv)",

@@ -6,7 +6,8 @@
  * mic_search_knc_ap_multiple_chunks (MICsearch.c:53-346): one host thread per device, each device
  * gets its chunks, queries and matrix are replicated, results are merged on the host -- except that
  * the chunk-to-device assignment is static (longest-first onto the least-loaded GPU) and only the
- * top-r rows per query come back instead of every score.
+ * top-r rows per query come back instead of every score.  Mode 2 (host + GPUs) is the reference's dynamic scheme
+ * (HETsearch.c:57,96-104): one work queue, the host team at its short end and the GPU workers at its long end.
  */
 #define _GNU_SOURCE
 #include <omp.h>
@@ -167,134 +168,237 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
     st->seconds = swimm_wtime() - tick;
 }
 
+/* ---- Mode 2: host and devices pull work from ONE queue (the reference's het_search_*, HETsearch.c:57 `num_threads(num_mics+1)`,
+ * :96-104 `omp for schedule(dynamic)` over the chunks, :337-342 the per-side chunk counts).
+ *
+ * The queue is the length-sorted database itself with a cursor at either end: the host team claims blocks of whole
+ * 128-sequence groups from the SHORT end (where a CPU core is at its best and a GPU wave at its worst), the GPU workers
+ * claim slabs from the LONG end, and the search is over when the two cursors meet -- no probe, no split fixed in
+ * advance: whichever side is faster simply ends up with more of the database, and both legs end within one grain of
+ * each other.  Grains: a GPU slab is min(-k, half the worker's fair share of what is left), never below a few
+ * milliseconds of GPU work, so the slabs shrink towards the end; a host block is sized for about 4 ms of the team's measured rate.
+ * Every device is served by two workers (two contexts, two host threads), so that one slab's copy and tiling overlap
+ * the other's alignment (the transfer the reference leaves synchronous, MICsearch.c:85-91). */
 typedef struct {
-    const swimm_hip_api *api; const swimm_options *o; const swimm_queries *q; const char *submat;
-    const uint16_t *lengths; const char *codes; uint64_t count, first; unsigned long top;
-    int32_t *part_s; int64_t *part_i; leg_stats *st;
-} gpu_leg_args;
+    pthread_mutex_t mu;
+    const uint16_t *lengths;
+    uint64_t lo, hi;              /* unclaimed sequences: [lo, hi) of the sorted database; lo is a multiple of 128 */
+    uint64_t res_lo, res_hi;      /* residue offsets of lo and hi in the .seq codes */
+    uint64_t host_cap, gpu_floor; /* test hook (a fixed host share): the host stops at host_cap, the GPUs at gpu_floor */
+    uint64_t left_res;            /* residues still unclaimed */
+    double host_rate;             /* residues per second the host team has been seen to do (0 = not yet known) ... */
+    double gpu_rate[64];          /* ... and every GPU worker (slab after slab; 0 = not yet known) */
+    int workers;
+} work_queue;
 
-static void *gpu_leg_thread(void *p)
+typedef struct { uint64_t first, count, offset, residues; } claim_t;
+
+static int claim_host(work_queue *wq, uint64_t want_residues, claim_t *c)
 {
-    gpu_leg_args *a = (gpu_leg_args *)p;
-    gpu_leg(a->api, a->o, a->q, a->submat, a->lengths, a->codes, a->count, a->first, a->top, a->part_s, a->part_i, a->st);
+    pthread_mutex_lock(&wq->mu);
+    const uint64_t end = wq->hi < wq->host_cap ? wq->hi : wq->host_cap;
+    int got = 0;
+    if (wq->lo < end) {
+        c->first = wq->lo; c->offset = wq->res_lo; c->residues = 0;
+        uint64_t i = wq->lo;
+        do {
+            const uint64_t e = i + 128 < end ? i + 128 : end;
+            for (; i < e; ++i) c->residues += wq->lengths[i];
+        } while (i < end && c->residues < want_residues);
+        c->count = i - wq->lo;
+        wq->lo = i; wq->res_lo += c->residues; wq->left_res -= c->residues;
+        got = 1;
+    }
+    pthread_mutex_unlock(&wq->mu);
+    return got;
+}
+
+/* Guided self-scheduling between workers of very different speed: a worker's slab is HALF its share of what is left, the
+ * shares in proportion to the rates measured so far (its own last slabs, the other workers', the host team's).  A worker
+ * whose rate is not known yet takes the smallest slab -- a few milliseconds of GPU work -- and is measured on it. */
+static int claim_gpu(work_queue *wq, uint64_t max_residues, uint64_t min_residues, int me, double my_last_rate, claim_t *c)
+{
+    pthread_mutex_lock(&wq->mu);
+    const uint64_t floor_ = wq->lo > wq->gpu_floor ? wq->lo : wq->gpu_floor;
+    int got = 0;
+    if (my_last_rate > 0) wq->gpu_rate[me] = wq->gpu_rate[me] > 0 ? 0.5 * (wq->gpu_rate[me] + my_last_rate) : my_last_rate;
+    if (wq->hi > floor_) {
+        double total = wq->host_cap > wq->lo ? wq->host_rate : 0;
+        for (int i = 0; i < wq->workers; ++i) total += wq->gpu_rate[i] > 0 ? wq->gpu_rate[i] : wq->gpu_rate[me];   /* (unknown: like me) */
+        uint64_t want = wq->gpu_rate[me] > 0 ? (uint64_t)(0.5 * (double)wq->left_res * wq->gpu_rate[me] / total) : 0;
+        if (want > max_residues) want = max_residues;
+        if (want < min_residues) want = min_residues;
+        uint64_t b = wq->hi, res = 0;
+        do {                                                          /* slab boundaries are multiples of 128 sequences */
+            uint64_t nb = (b - 1) / 128 * 128;
+            if (nb < floor_) nb = floor_;
+            for (uint64_t i = nb; i < b; ++i) res += wq->lengths[i];
+            b = nb;
+        } while (b > floor_ && res < want && res < 0xE0000000ull);
+        c->first = b; c->count = wq->hi - b; c->residues = res; c->offset = wq->res_hi - res;
+        wq->hi = b; wq->res_hi -= res; wq->left_res -= res;
+        got = 1;
+    }
+    pthread_mutex_unlock(&wq->mu);
+    return got;
+}
+
+/* running top-r list of one worker: new = merge(old, part) */
+static void fold_lists(int32_t *run_s, int64_t *run_i, const int32_t *part_s, const int64_t *part_i, uint64_t queries, unsigned long top)
+{
+    int32_t *ls = (int32_t *)malloc(2 * top * sizeof(int32_t)), *os = (int32_t *)malloc(top * sizeof(int32_t));
+    int64_t *li = (int64_t *)malloc(2 * top * sizeof(int64_t)), *oi = (int64_t *)malloc(top * sizeof(int64_t));
+    for (uint64_t q = 0; q < queries; ++q) {
+        memcpy(ls, run_s + q * top, top * sizeof(int32_t)); memcpy(ls + top, part_s + q * top, top * sizeof(int32_t));
+        memcpy(li, run_i + q * top, top * sizeof(int64_t)); memcpy(li + top, part_i + q * top, top * sizeof(int64_t));
+        swimm_topr_merge(ls, li, 2, (uint32_t)top, os, oi);
+        memcpy(run_s + q * top, os, top * sizeof(int32_t)); memcpy(run_i + q * top, oi, top * sizeof(int64_t));
+    }
+    free(ls); free(os); free(li); free(oi);
+}
+
+typedef struct {
+    const swimm_hip_api *api; const swimm_options *o; const swimm_queries *q; const char *submat; const swimm_db *db;
+    work_queue *wq; int device, index; unsigned long top; double tick; uint64_t min_slab;
+    int32_t *run_s; int64_t *run_i;          /* [query][top], global indices */
+    uint64_t sequences, claims, promoted; double kernel_ms, end_s; char err[512];
+} gpu_worker;
+
+static void *gpu_worker_main(void *p)
+{
+    gpu_worker *w = (gpu_worker *)p;
+    const swimm_hip_api *api = w->api;
+    const swimm_queries *q = w->q;
+    swimm_hip_ctx *ctx = NULL;
+    int32_t *ps = (int32_t *)malloc(q->count * w->top * sizeof(int32_t));
+    int64_t *pi = (int64_t *)malloc(q->count * w->top * sizeof(int64_t));
+    int bad = api->create(w->device, &ctx);
+    if (!bad) bad = api->set_option(ctx, "lazy_upload", 1);     /* the slab streams in piece by piece while the search runs */
+    if (!bad) bad = api->set_queries(ctx, q->a, q->m, q->disp, (uint32_t)q->count, w->submat, w->o->open_gap, w->o->extend_gap);
+    claim_t c;
+    double rate = 0;
+    while (!bad && claim_gpu(w->wq, (uint64_t)w->o->max_chunk_size, w->min_slab, w->index, rate, &c)) {
+        const double t0 = swimm_wtime();
+        if (w->claims && api->clear_db(ctx)) { bad = 1; break; }
+        if (api->add_sequences(ctx, w->db->lengths + c.first, w->db->codes + c.offset, c.count, c.first)) { bad = 1; break; }
+        if (api->search_topr(ctx, (uint32_t)w->top, w->db->count, ps, pi, NULL)) { bad = 1; break; }
+        fold_lists(w->run_s, w->run_i, ps, pi, q->count, w->top);
+        double kms = 0; uint64_t prom = 0;
+        api->last_stats(ctx, &kms, NULL, &prom, NULL);
+        w->kernel_ms += kms; w->promoted += prom;
+        w->sequences += c.count; w->claims++;
+        w->end_s = swimm_wtime() - w->tick;
+        rate = (double)c.residues / (swimm_wtime() - t0 > 1e-6 ? swimm_wtime() - t0 : 1e-6);
+        if (getenv("SWIMM_DEBUG"))
+            fprintf(stderr, "swimm: GPU %d: slab of %llu sequences from %llu (%.1f MB) done at %.4f s\n", w->device, (unsigned long long)c.count,
+                    (unsigned long long)c.first, c.residues / 1e6, w->end_s);
+    }
+    if (bad) snprintf(w->err, sizeof w->err, "%s", api->last_error());
+    if (ctx) api->destroy(ctx);
+    free(ps); free(pi);
     return NULL;
 }
 
-/* Mode 2 (the reference's het_search_*, HETsearch.c:57,96-104: host and devices pull chunks from one queue): here
- * the split is fixed before the search, because the GPUs keep their share resident and search it in one go.  Both
- * rates are MEASURED before the clock starts: the host's on a sample of the shortest sequences with the shortest
- * query, the GPU's by a probe search of the real query batch against a sample from the long end of the database
- * on device 0 (context creation and upload are timed too).  The host gets the shortest sequences it can finish in
- * the time the GPUs need for the rest.  Returns the number of sequences for the host (0: not worth it). */
-static uint64_t hybrid_split(const swimm_hip_api *api, const swimm_options *o, const swimm_queries *q, const char *submat, const swimm_db *db, int G)
+typedef struct { uint64_t n_cpu, n_gpu, gpu_claims, cpu_claims; } hybrid_counts;
+
+static void hybrid_search(const swimm_hip_api *api, const swimm_options *o, const swimm_queries *q, const char *submat, const swimm_db *db,
+                          unsigned long top, int32_t *top_scores, int64_t *top_idx, leg_stats *gst, leg_stats *cst, hybrid_counts *hc)
 {
-    const uint64_t vl = (uint64_t)o->vector_length;
-    const char *forced = getenv("SWIMM_HYBRID_CPU_SEQUENCES");   /* test hook: fixed host share */
+    const int G = o->num_gpus;
+    work_queue wq;
+    pthread_mutex_init(&wq.mu, NULL);
+    wq.lengths = db->lengths; wq.lo = 0; wq.hi = db->count; wq.res_lo = 0; wq.res_hi = db->residues; wq.left_res = db->residues;
+    wq.host_cap = db->count; wq.gpu_floor = 0; wq.host_rate = 0;
+    memset(wq.gpu_rate, 0, sizeof wq.gpu_rate);
+    const char *forced = getenv("SWIMM_HYBRID_CPU_SEQUENCES");   /* test hook: a fixed host share (the first n sequences) */
     if (forced) {
         uint64_t n = strtoull(forced, NULL, 10) / 128 * 128;
-        return n < db->count ? n : 0;
+        if (n >= db->count) n = 0;
+        wq.host_cap = wq.gpu_floor = n;
     }
-    uint64_t sample = 0, sample_res = 0;
-    while (sample < db->count && sample_res * q->Q < 2000000000ull) sample_res += db->lengths[sample++];
-    sample = (sample + vl - 1) / vl * vl;
-    if (sample == 0 || sample >= db->count) return 0;
-    swimm_queries q0 = *q;                          /* the whole batch: the host's rate depends on the query length */
-    leg_stats st = {0, 0, 0, 0};
-    int32_t *s1 = (int32_t *)malloc(q->count * sizeof(int32_t));
-    int64_t *i1 = (int64_t *)malloc(q->count * sizeof(int64_t));
-    swimm_single_chunk sc;
-    int rc = swimm_assemble_single_chunk(db->lengths, db->codes, sample, o->vector_length, o->cpu_block_size, &sc);
-    if (rc) die_host(rc);
-    cpu_leg(o, &q0, submat, &sc, sample, 1, s1, i1, &st);      /* wakes the thread team */
-    st.seconds = 0;
-    cpu_leg(o, &q0, submat, &sc, sample, 1, s1, i1, &st);
-    swimm_single_chunk_free(&sc);
-    sample_res = 0;
-    for (uint64_t i = 0; i < sample; ++i) sample_res += db->lengths[i];
-    free(s1); free(i1);
-    const double host_rate = (double)sample_res * (double)q->Q / (st.seconds > 1e-6 ? st.seconds : 1e-6);   /* cells per second */
-
-    /* GPU probe: the last sequences of the sorted database (the GPUs' end), at most 64 MB of residues */
-    uint64_t pn = 0, pres = 0;
-    while (pn < db->count - sample && pres < (64ull << 20)) pres += db->lengths[db->count - 1 - pn++];
-    pn = pn / 128 * 128;
-    if (pn == 0) return 0;
-    pres = 0;
-    for (uint64_t i = db->count - pn; i < db->count; ++i) pres += db->lengths[i];
-    const double Qrows = (double)q->Q;
-    double t_ctx = 0, t_up = 0, t_search = 0, t_first = 0;
-    {
-        swimm_hip_ctx *ctx = NULL;
+    /* the smallest slab: what a GPU aligns in a few milliseconds (2e10 cells), so that a slab's fixed costs -- buffers, the
+     * first piece's copy, launches, the top-r pass -- stay a small part of it */
+    uint64_t min_slab = 20000000000ull / (q->Q ? q->Q : 1);
+    if (min_slab < (256u << 10)) min_slab = 256u << 10;
+    if (min_slab > (64u << 20)) min_slab = 64u << 20;
+    if (getenv("SWIMM_HYBRID_MIN_SLAB")) min_slab = strtoull(getenv("SWIMM_HYBRID_MIN_SLAB"), NULL, 10);   /* test hook */
+    /* two workers per device when the database is more than a few slabs' worth (else one: a second context only costs) */
+    const int per_dev = db->residues > 4 * min_slab ? 2 : 1;
+    const int NW = G * per_dev > 64 ? 64 : G * per_dev;
+    wq.workers = NW;
+    gpu_worker *gw = (gpu_worker *)calloc((size_t)NW, sizeof(gpu_worker));
+    pthread_t *th = (pthread_t *)malloc((size_t)NW * sizeof(pthread_t));
+    const size_t list = q->count * top;
+    const double tick = swimm_wtime();
+    for (int i = 0; i < NW; ++i) {
+        gpu_worker *w = &gw[i];
+        w->api = api; w->o = o; w->q = q; w->submat = submat; w->db = db; w->wq = &wq; w->device = i % G; w->index = i; w->top = top; w->tick = tick; w->min_slab = min_slab;
+        w->run_s = (int32_t *)malloc(list * sizeof(int32_t)); w->run_i = (int64_t *)malloc(list * sizeof(int64_t));
+        for (size_t k = 0; k < list; ++k) { w->run_s[k] = -1; w->run_i[k] = -1; }
+        if (pthread_create(&th[i], NULL, gpu_worker_main, w)) { printf("SWIMM: cannot start a GPU thread.\n"); exit(1); }
+    }
+    /* the host leg on this thread, with the ordinary (top-level, warm) OpenMP team */
+    int32_t *hs = (int32_t *)malloc(list * sizeof(int32_t)), *bs = (int32_t *)malloc(list * sizeof(int32_t));
+    int64_t *hi_ = (int64_t *)malloc(list * sizeof(int64_t)), *bi = (int64_t *)malloc(list * sizeof(int64_t));
+    for (size_t k = 0; k < list; ++k) { hs[k] = -1; hi_[k] = -1; }
+    double host_rate = 0;                            /* cells per second, measured block by block */
+    claim_t c;
+    uint64_t want = 200000000ull / (q->Q ? q->Q : 1) + 1;        /* first block: 2e8 cells */
+    while (claim_host(&wq, want, &c)) {
         const double t0 = swimm_wtime();
-        int bad = api->create(0, &ctx);
-        t_ctx = swimm_wtime() - t0;
-        if (!bad) bad = api->set_queries(ctx, q->a, q->m, q->disp, (uint32_t)q->count, submat, o->open_gap, o->extend_gap);
-        const double t1 = swimm_wtime();
-        if (!bad) bad = api->add_sequences(ctx, db->lengths + (db->count - pn), db->codes + (db->residues - pres), pn, 0);
-        t_up = swimm_wtime() - t1;
-        int32_t *ps = (int32_t *)malloc(q->count * sizeof(int32_t));
-        int64_t *pi = (int64_t *)malloc(q->count * sizeof(int64_t));
-        if (!bad) bad = api->search_topr(ctx, 1, pn, ps, pi, NULL);          /* builds the work lists, warms the code objects */
-        const double t2 = swimm_wtime();
-        t_first = t2 - (t1 + t_up);
-        if (!bad) bad = api->search_topr(ctx, 1, pn, ps, pi, NULL);
-        t_search = swimm_wtime() - t2;
-        free(ps); free(pi);
-        if (bad) { printf("SWIMM: GPU probe failed: %s\n", api->last_error()); exit(5); }
-        api->destroy(ctx);
+        swimm_single_chunk sc;
+        int rc = swimm_assemble_single_chunk(db->lengths + c.first, db->codes + c.offset, c.count, o->vector_length, o->cpu_block_size, &sc);
+        if (rc) die_host(rc);
+        leg_stats st = {0, 0, 0, 0};
+        cpu_leg(o, q, submat, &sc, c.count, top, bs, bi, &st);
+        swimm_single_chunk_free(&sc);
+        for (size_t k = 0; k < list; ++k) if (bi[k] >= 0) bi[k] += (int64_t)c.first;
+        fold_lists(hs, hi_, bs, bi, q->count, top);
+        const double dt = swimm_wtime() - t0;
+        const double rate = (double)c.residues * (double)q->Q / (dt > 1e-6 ? dt : 1e-6);
+        host_rate = host_rate > 0 ? 0.5 * (host_rate + rate) : rate;
+        pthread_mutex_lock(&wq.mu);
+        wq.host_rate = host_rate / (double)(q->Q ? q->Q : 1);
+        pthread_mutex_unlock(&wq.mu);
+        want = (uint64_t)(host_rate * 0.004 / (double)(q->Q ? q->Q : 1)) + 1;      /* about 4 ms of the team's time */
+        hc->n_cpu += c.count; hc->cpu_claims++;
+        cst->seconds = swimm_wtime() - tick;
     }
-    const double gpu_rate = Qrows * (double)pres / (t_search > 1e-6 ? t_search : 1e-6) * G;     /* cells per second, all devices */
-    const double up_rate = (double)pres / (t_up > 1e-6 ? t_up : 1e-6);                            /* bytes per second per device */
-    /* the GPUs' time for x cells: context + the longer of upload and search (slabs stream in while the search runs) */
-    const double total = Qrows * (double)db->residues;
-    const double t_upload = (double)db->residues / G / up_rate;
-    /* what a first search costs beyond the alignment itself (work lists, buffers), per database byte */
-    const double t_setup = (t_first > t_search ? t_first - t_search : 0.0) / (double)pres * (double)db->residues / G;
-    const double fixed = t_ctx + t_setup;
-    /* host_cells / host_rate = fixed + max(t_upload, (total - host_cells) / gpu_rate) */
-    double host_cells = (fixed + total / gpu_rate) / (1.0 / host_rate + 1.0 / gpu_rate);
-    if ((total - host_cells) / gpu_rate < t_upload) host_cells = (fixed + t_upload) * host_rate;
-    if (host_cells > 0.5 * total) host_cells = 0.5 * total;
-    if (getenv("SWIMM_DEBUG"))
-        fprintf(stderr, "swimm: hybrid probe: host %.2f GCUPS; GPU context %.3f s, setup %.3f s, upload %.1f GB/s, search %.1f GCUPS per device -> host share %.3g of %.3g cells\n",
-                host_rate / 1e9, t_ctx, t_setup, up_rate / 1e9, gpu_rate / G / 1e9, host_cells, total);
-    uint64_t n = 0, res = 0;
-    while (n < db->count && (double)(res + db->lengths[n]) * Qrows <= host_cells) res += db->lengths[n++];
-    /* The host's rate depends on the sequence length (the sample above was the very shortest sequences), and most of its
-     * share's cells sit at the long end of the share: measure again there and size the share with that rate. */
-    if (n > 2 * sample) {
-        /* long enough (about 0.4 s at the first probe's rate) to see the rate the host SUSTAINS: on the test box a burst of
-         * 10 ms ran 3.5x faster than a second of the same work (shared host, CPU quota), and the share is sized for a leg
-         * that lasts as long as the GPUs' */
-        const double target_cells = 0.4 * host_rate;
-        uint64_t w = 0, wres = 0;
-        while (w < n && (double)wres * (double)q->Q < target_cells) wres += db->lengths[n - 1 - w++];
-        w = w / vl * vl;
-        if (w >= vl) {
-            const uint64_t first = (n - w) / vl * vl;
-            uint64_t off = 0;
-            for (uint64_t i = 0; i < first; ++i) off += db->lengths[i];
-            wres = 0;
-            for (uint64_t i = first; i < first + w; ++i) wres += db->lengths[i];
-            rc = swimm_assemble_single_chunk(db->lengths + first, db->codes + off, w, o->vector_length, o->cpu_block_size, &sc);
-            if (rc) die_host(rc);
-            int32_t *s2 = (int32_t *)malloc(q->count * sizeof(int32_t));
-            int64_t *i2 = (int64_t *)malloc(q->count * sizeof(int64_t));
-            st.seconds = 0;
-            cpu_leg(o, &q0, submat, &sc, w, 1, s2, i2, &st);
-            free(s2); free(i2);
-            swimm_single_chunk_free(&sc);
-            const double rate2 = (double)wres * (double)q->Q / (st.seconds > 1e-6 ? st.seconds : 1e-6);
-            host_cells = (fixed + total / gpu_rate) / (1.0 / rate2 + 1.0 / gpu_rate);
-            if ((total - host_cells) / gpu_rate < t_upload) host_cells = (fixed + t_upload) * rate2;
-            if (host_cells > 0.5 * total) host_cells = 0.5 * total;
-            if (getenv("SWIMM_DEBUG")) fprintf(stderr, "swimm: hybrid probe: host at the far end of its share %.2f GCUPS -> %.3g cells\n", rate2 / 1e9, host_cells);
-            n = 0; res = 0;
-            while (n < db->count && (double)(res + db->lengths[n]) * Qrows <= host_cells) res += db->lengths[n++];
+    for (int i = 0; i < NW; ++i) pthread_join(th[i], NULL);
+    for (int i = 0; i < NW; ++i) if (gw[i].err[0]) { printf("SWIMM: GPU %d: %s\n", gw[i].device, gw[i].err); exit(5); }
+    if (wq.lo < wq.hi) { printf("SWIMM: %llu sequences were not searched.\n", (unsigned long long)(wq.hi - wq.lo)); exit(5); }
+    /* host k-way merge of the workers' lists and the host's */
+    const int lists = NW + 1;
+    int32_t *ls = (int32_t *)malloc((size_t)lists * top * sizeof(int32_t));
+    int64_t *li = (int64_t *)malloc((size_t)lists * top * sizeof(int64_t));
+    for (uint64_t k = 0; k < q->count; ++k) {
+        for (int g = 0; g < NW; ++g) {
+            memcpy(ls + (size_t)g * top, gw[g].run_s + k * top, top * sizeof(int32_t));
+            memcpy(li + (size_t)g * top, gw[g].run_i + k * top, top * sizeof(int64_t));
         }
+        memcpy(ls + (size_t)NW * top, hs + k * top, top * sizeof(int32_t));
+        memcpy(li + (size_t)NW * top, hi_ + k * top, top * sizeof(int64_t));
+        swimm_topr_merge(ls, li, (uint32_t)lists, (uint32_t)top, top_scores + k * top, top_idx + k * top);
     }
-    n = n / 128 * 128;                               /* the GPU part keeps whole lane groups */
-    return n >= vl && n < db->count ? n : 0;
+    for (int i = 0; i < NW; ++i) {
+        gpu_worker *w = &gw[i];
+        hc->n_gpu += w->sequences; hc->gpu_claims += w->claims; gst->promoted += w->promoted;
+        if (w->end_s > gst->seconds) gst->seconds = w->end_s;
+        free(w->run_s); free(w->run_i);
+    }
+    /* kernel time per device = the sum over its workers' slabs (they share the device) */
+    for (int d = 0; d < G; ++d) {
+        double kms = 0;
+        for (int i = d; i < NW; i += G) kms += gw[i].kernel_ms;
+        if (kms > gst->kernel_ms) gst->kernel_ms = kms;
+    }
+    gst->chunk_count = (uint32_t)hc->gpu_claims;
+    if (getenv("SWIMM_DEBUG"))
+        fprintf(stderr, "swimm: hybrid queue: host %llu sequences in %llu blocks (%.3f s, %.1f GCUPS at the end), GPUs %llu sequences in %llu slabs (%.3f s)\n",
+                (unsigned long long)hc->n_cpu, (unsigned long long)hc->cpu_claims, cst->seconds, host_rate / 1e9, (unsigned long long)hc->n_gpu,
+                (unsigned long long)hc->gpu_claims, gst->seconds);
+    free(ls); free(li); free(hs); free(hi_); free(bs); free(bi); free(gw); free(th);
+    pthread_mutex_destroy(&wq.mu);
 }
 
 int main(int argc, char **argv)
@@ -333,6 +437,7 @@ int main(int argc, char **argv)
     double workTime = 0;
     leg_stats gst = {0, 0, 0, 0}, cst = {0, 0, 0, 0};
     uint64_t n_cpu = 0;          /* sequences (from the short end of the sorted database) searched on the host */
+    hybrid_counts hc = {0, 0, 0, 0};
     omp_set_num_threads(o.cpu_threads);
 
     if (o.execution_mode == MODE_CPU_ONLY) {
@@ -349,39 +454,31 @@ int main(int argc, char **argv)
         if (avail <= 0) { printf("SWIMM: no MI355X visible: %s\n", api.last_error()); exit(5); }
         if (o.num_gpus > avail) { printf("SWIMM: %d GPUs requested, %d visible.\n", o.num_gpus, avail); exit(5); }
         const int G = o.num_gpus;
-        if (o.execution_mode == MODE_HYBRID) n_cpu = hybrid_split(&api, &o, &q, submat, &db, G);
-        const uint64_t n_gpu = db.count - n_cpu;
-        uint64_t cpu_residues = 0;
-        for (uint64_t i = 0; i < n_cpu; ++i) cpu_residues += db.lengths[i];
-        const int lists = G + (n_cpu ? 1 : 0);
-        int32_t *part_s = (int32_t *)malloc((size_t)lists * q.count * top * sizeof(int32_t));
-        int64_t *part_i = (int64_t *)malloc((size_t)lists * q.count * top * sizeof(int64_t));
-        if (!part_s || !part_i) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
-        for (size_t i = 0; i < (size_t)lists * q.count * top; ++i) { part_s[i] = -1; part_i[i] = -1; }
-        swimm_single_chunk sc;      /* the host's lane layout is built before the clock starts (swimm.c:46 precedes the search call) */
-        if (n_cpu && (rc = swimm_assemble_single_chunk(db.lengths, db.codes, n_cpu, o.vector_length, o.cpu_block_size, &sc))) die_host(rc);
-        const double tick = swimm_wtime();   /* brackets transfers + kernels + merge, like MICsearch.c:51,350 */
-        /* The GPU leg on a thread of its own, the host's share on this one with the ordinary (warm, top-level) OpenMP team
-         * -- the same conditions under which hybrid_split measured the host's rate; a nested team started cold ran at half
-         * of it. */
-        gpu_leg_args ga = {&api, &o, &q, submat, db.lengths + n_cpu, db.codes + cpu_residues, n_gpu, n_cpu, top, part_s, part_i, &gst};
-        pthread_t gpu_thread;
-        if (pthread_create(&gpu_thread, NULL, gpu_leg_thread, &ga)) { printf("SWIMM: cannot start the GPU thread.\n"); exit(1); }
-        if (n_cpu) cpu_leg(&o, &q, submat, &sc, n_cpu, top, part_s + (size_t)G * q.count * top, part_i + (size_t)G * q.count * top, &cst);
-        pthread_join(gpu_thread, NULL);
-        if (n_cpu) swimm_single_chunk_free(&sc);
-        /* host k-way merge of the per-device lists ([lists][query][top]) */
-        int32_t *ls = (int32_t *)malloc((size_t)lists * top * sizeof(int32_t));
-        int64_t *li = (int64_t *)malloc((size_t)lists * top * sizeof(int64_t));
-        for (uint64_t i = 0; i < q.count; ++i) {
-            for (int g = 0; g < lists; ++g) {
-                memcpy(ls + (size_t)g * top, part_s + ((size_t)g * q.count + i) * top, top * sizeof(int32_t));
-                memcpy(li + (size_t)g * top, part_i + ((size_t)g * q.count + i) * top, top * sizeof(int64_t));
+        if (o.execution_mode == MODE_HYBRID) {
+            const double tick = swimm_wtime();   /* brackets context creation + transfers + kernels + host blocks + merge */
+            hybrid_search(&api, &o, &q, submat, &db, top, top_scores, top_idx, &gst, &cst, &hc);
+            workTime = swimm_wtime() - tick;
+            n_cpu = hc.n_cpu;
+        } else {
+            int32_t *part_s = (int32_t *)malloc((size_t)G * q.count * top * sizeof(int32_t));
+            int64_t *part_i = (int64_t *)malloc((size_t)G * q.count * top * sizeof(int64_t));
+            if (!part_s || !part_i) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
+            for (size_t i = 0; i < (size_t)G * q.count * top; ++i) { part_s[i] = -1; part_i[i] = -1; }
+            const double tick = swimm_wtime();   /* brackets transfers + kernels + merge, like MICsearch.c:51,350 */
+            gpu_leg(&api, &o, &q, submat, db.lengths, db.codes, db.count, 0, top, part_s, part_i, &gst);
+            /* host k-way merge of the per-device lists ([device][query][top]) */
+            int32_t *ls = (int32_t *)malloc((size_t)G * top * sizeof(int32_t));
+            int64_t *li = (int64_t *)malloc((size_t)G * top * sizeof(int64_t));
+            for (uint64_t i = 0; i < q.count; ++i) {
+                for (int g = 0; g < G; ++g) {
+                    memcpy(ls + (size_t)g * top, part_s + ((size_t)g * q.count + i) * top, top * sizeof(int32_t));
+                    memcpy(li + (size_t)g * top, part_i + ((size_t)g * q.count + i) * top, top * sizeof(int64_t));
+                }
+                swimm_topr_merge(ls, li, (uint32_t)G, (uint32_t)top, top_scores + i * top, top_idx + i * top);
             }
-            swimm_topr_merge(ls, li, (uint32_t)lists, (uint32_t)top, top_scores + i * top, top_idx + i * top);
+            workTime = swimm_wtime() - tick;
+            free(ls); free(li); free(part_s); free(part_i);
         }
-        workTime = swimm_wtime() - tick;
-        free(ls); free(li); free(part_s); free(part_i);
     }
 
     /* titles of the reported hits only (the reference loads all N, sequences.c:757-761) */
@@ -413,9 +510,11 @@ int main(int argc, char **argv)
         printf("Chunk count:\t\t\t%ld \n", (long)gst.chunk_count);
         printf("Kernel time:\t\t\t%lf seconds\n", gst.kernel_ms / 1000.0);
         printf("Promoted to int32:\t\t%ld alignments\n", (long)gst.promoted);
-        if (o.execution_mode == MODE_HYBRID)   /* the reference prints "%d chunks in CPU and %d in MICs" (HETsearch.c:337-342) */
+        if (o.execution_mode == MODE_HYBRID) {   /* the reference prints "%d chunks in CPU and %d in MICs" (HETsearch.c:337-342) */
             printf("Host CPU share:\t\t\t%ld sequences (%.3lf seconds), MI355X %ld sequences (%.3lf seconds)\n", (long)n_cpu, cst.seconds,
                    (long)(db.count - n_cpu), gst.seconds);
+            printf("Work queue:\t\t\t%ld blocks in CPU and %ld slabs in MI355X\n", (long)hc.cpu_claims, (long)hc.gpu_claims);
+        }
     }
     for (uint64_t i = 0; i < q.count * top; ++i) free(titles[i]);
     free(titles); free(top_scores); free(top_idx);

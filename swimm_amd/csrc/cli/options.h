@@ -7,7 +7,7 @@
 
 #define MODE_CPU_ONLY 0      /* -m 0 : host CPU (explicit; never a fallback) */
 #define MODE_GPU_ONLY 1      /* -m 1 : MI355X only (the reference's "Xeon Phi only") */
-#define MODE_HYBRID 2        /* -m 2 : host CPU and MI355X concurrently (static split, see hybrid_split) */
+#define MODE_HYBRID 2        /* -m 2 : host CPU and MI355X concurrently, one work queue (hybrid_search) */
 
 typedef struct {
     const char *op;               /* -S preprocess | search */

@@ -136,6 +136,9 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    touches; no launch boundary).  -1 = default: formed when the call has two or more
  *                    queries (or streams its database in) and the database is small beside the chip; 0 = never: one launch
  *                    per pass of every query ("split", "bnd_mib" apply); 1 = always, every query joins
+ *   "stack"          1 = default: short queries (up to 72 rows) of a batch share workgroups -- two to four of them stacked along the
+ *                    strips of one 4-wave workgroup, each with its own score row -- instead of padding each to a launch
+ *                    shape of its own; 0 = every query its own workgroups
  *   "lane_room"      -1 = default: launch shapes leave a lane-systolic wave its registers when the database has a long-sequence
  *                    tail; 0 = never; 1 = always
  *   "rotate"         1 = default: when no group-resident batch is formed, eight or more one-pass queries run whole on three

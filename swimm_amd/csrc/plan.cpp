@@ -56,6 +56,7 @@ hipStream_t list_stream(const swimm_hip_ctx *c) { return c->streaming_now ? c->s
 int list_copy(swimm_hip_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return 0;
+    CHECK_DEVICE(c);
     if (c->pin_used + bytes > c->pin_cap) {
         HIP_TRY(hipStreamSynchronize(list_stream(c)));        // copies in flight still read the arena
         c->pin_used = 0;
@@ -148,6 +149,8 @@ static const float kShapeGcups[8][16] = {
     {4130, 6470, 6405, 8592, 4870, 5827, 6764, 7683, 6120, 6796, 7444, 8120, 0, 0, 0, 0},                 // T=32
     {4144, 6660, 6398, 8523, 4902, 5900, 6674, 7809, 6154, 6874, 7083, 8217, 0, 0, 0, 0},                 // T=36
 };
+
+double shape_gcups(int T, int W) { return (T >= 8 && T <= 36 && T % 4 == 0 && W >= 1 && W <= 16) ? (double)kShapeGcups[(T - 8) / 4][W - 1] : 0.0; }
 
 // Rows per wave T, waves per workgroup W and number of passes for a query of m rows: the shape with the lowest
 // predicted time, passes x (padded cells of a pass / measured rate of that shape x makespan factor + launch cost).
@@ -462,6 +465,9 @@ void fill_common(const swimm_hip_ctx *c, const QueryPlan &qp, PipeParams &p, uin
     p.bnd = bnd;
     p.goe = c->open_gap + c->extend_gap;
     p.ge = c->extend_gap;
+    p.wave_out = qp.stack ? c->d_wave_out.p : nullptr;
+    p.seam_mask = qp.seam_mask;
+    p.wave_tab = qp.wave_tab;
 }
 
 // columns of boundary rows (64 lanes x 8 B each) the pass-boundary buffer may hold

@@ -53,6 +53,7 @@ int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl
     p.queue = c->d_queue.p + c->queue_next++;
     p.qdesc = qd;
     p.n_queries = nq;
+    p.wave_out = c->d_wave_out.p;
     p.bnd_wg_cols = pl.queue_cols[0];
     p.r0 = 0;
     p.first_pass = 1; p.last_pass = 0;
@@ -259,6 +260,16 @@ struct SearchRun {
     std::vector<uint8_t> rotated;                            // one-pass queries that run whole (no tail kernel) on three streams in rotation
     std::vector<uint8_t> in_batch;                           // queries of the group-resident batch launches
     std::vector<QueryPlan> one_plan = std::vector<QueryPlan>(1);
+    // Stacks: short one-pass queries of a batch that share workgroups -- the members' strips one after the other along the
+    // waves of one 4-wave workgroup, every member padded to whole strips, a zero boundary at every seam, one score row per
+    // member (sw_kernels.h, QDesc).  A 40-row query alone fills 40 of a 4 x 12-row workgroup's 48 rows at that shape's 7 340
+    // GCUPS, or 40 of 2 x 20 at 5 890; two of them stacked fill 80 of 4 x 20 rows at 8 260.
+    struct Stack { int T = 0, W = 4; bool resident = false; size_t prof_off = 0; uint32_t rows = 0, seam_mask = 0, wave_tab = 0;
+                   std::vector<uint32_t> q, strip0, nstrips; };
+    std::vector<Stack> stacks;
+    std::vector<int> stack_of;                               // per query: its stack, or -1
+    struct Unit { int stack; uint32_t q; };                  // an entry of a group-resident launch's query table: a stack, or a query
+    std::map<std::pair<int, int>, std::vector<Unit>> by_shape;
     std::vector<std::vector<QueryPlan>> rqps;                // streaming, per-pass launches: a launch shape per (range, query)
     size_t prof_elems = 0;
     int tail_lanes = 1;                     // tail launches in flight at a time (decided with the buffer sizes)
@@ -285,6 +296,8 @@ struct SearchRun {
     }
     const QueryPlan &qp_of(size_t ri, uint32_t q) const { return rqps.empty() ? qps[q] : rqps[ri][q]; }
     int plan_of(size_t ri, uint32_t q, DbPlan **out);
+    int plan_for(size_t ri, int T, int W, bool resident, bool whole_db, DbPlan **out);
+    int build_stacks();
 
     int begin(uint64_t *slots_out);
     int layout_ranges();
@@ -301,21 +314,80 @@ struct SearchRun {
 };
 
 // the work lists of a (range, launch shape): cached for the resident database, temporary for a streaming chunk
-int SearchRun::plan_of(size_t ri, uint32_t q, DbPlan **out)
+int SearchRun::plan_for(size_t ri, int T, int W, bool resident, bool whole_db, DbPlan **out)
 {
     int per_cu = 1;
-    if (wgs_per_cu(c, main_mode, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, &per_cu)) return 1;
+    if (wgs_per_cu(c, main_mode, T, W, resident, &per_cu)) return 1;
     const int n_wg = n_workgroups(c, per_cu);
-    if (!streaming) return get_db_plan(c, main_mode, n_wg, rotated[q] != 0 || qps[q].resident, out);
+    if (!streaming) return get_db_plan(c, main_mode, n_wg, whole_db, out);
     auto it = stream_plans[ri].find(n_wg);
     if (it == stream_plans[ri].end()) {
         DbPlan &dp = stream_plans[ri][n_wg];
         bool exact = true;
         for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[up_order[ci]].lens_known;
-        if (make_db_plan(c, main_mode, n_wg, qps[q].resident, ranges[ri], exact, dp)) return 1;
+        if (make_db_plan(c, main_mode, n_wg, resident, ranges[ri], exact, dp)) return 1;
         *out = &dp;
     } else {
         *out = &it->second;
+    }
+    return 0;
+}
+
+int SearchRun::plan_of(size_t ri, uint32_t q, DbPlan **out)
+{
+    return plan_for(ri, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, rotated[q] != 0 || qps[q].resident, out);
+}
+
+// Which short queries share workgroups.  Candidates: the one-pass queries of up to 72 rows that run without a tail kernel
+// anyway (members of the group-resident batch, or in rotation).  Every candidate takes s = 1 or 2 strips of the height T that
+// costs it least (s x T rows at the measured rate of the 4 x T shape); the candidates of one height fill bins of four strips,
+// largest first; a bin that does not fill up is dissolved (its queries run as before).
+int SearchRun::build_stacks()
+{
+    stack_of.assign(qn, -1);
+    stacks.clear();
+    if (!c->opt_stack || !c->opt_dynamic || c->opt_T || c->opt_W || c->opt_maxW) return 0;   // (a forced launch shape is honoured query by query)
+    const int W = 4;
+    for (int pass = 0; pass < 2; ++pass) {               // the batch's members, then the rotating ones
+        std::map<int, std::vector<std::pair<int, uint32_t>>> cls;     // T -> (strips, query)
+        for (uint32_t q = 0; q < qn; ++q) {
+            if (!(pass == 0 ? in_batch[q] != 0 : rotated[q] != 0) || qm[q] > 72) continue;
+            int bt = 0, bs = 0;
+            double bc = 0;
+            for (int s = 1; s <= 2; ++s)
+                for (int T = 8; T <= 36; T += 4) {
+                    if (!pipe_has_variant(main_mode, T) || s * T < (int)qm[q]) continue;
+                    const double cost = (double)(s * T) / shape_gcups(T, W);
+                    if (!bt || cost < bc) { bt = T; bs = s; bc = cost; }
+                    break;                                   // (the lowest T that holds the query with s strips; taller only wastes rows)
+                }
+            if (bt) cls[bt].push_back({bs, q});
+        }
+        for (auto &kv : cls) {
+            auto &v = kv.second;
+            std::stable_sort(v.begin(), v.end(), [](const std::pair<int, uint32_t> &a, const std::pair<int, uint32_t> &b) { return a.first > b.first; });
+            std::vector<Stack> bins;
+            std::vector<int> used;
+            for (auto &e : v) {
+                size_t b = 0;
+                while (b < bins.size() && used[b] + e.first > W) ++b;
+                if (b == bins.size()) { bins.emplace_back(); used.push_back(0); bins[b].T = kv.first; bins[b].W = W; bins[b].resident = pass == 0; }
+                bins[b].q.push_back(e.second); bins[b].strip0.push_back((uint32_t)used[b]); bins[b].nstrips.push_back((uint32_t)e.first);
+                bins[b].seam_mask |= 1u << used[b];
+                used[b] += e.first;
+            }
+            for (size_t b = 0; b < bins.size(); ++b) {
+                if (used[b] < W || bins[b].q.size() < 2) continue;      // not full, or one query alone: as before
+                bins[b].rows = (uint32_t)(W * bins[b].T);
+                for (uint32_t q : bins[b].q) stack_of[q] = (int)stacks.size();
+                stacks.push_back(std::move(bins[b]));
+            }
+        }
+    }
+    if (dbg) {
+        size_t members = 0;
+        for (const Stack &st : stacks) members += st.q.size();
+        fprintf(stderr, "swimm_hip: %zu short queries stacked into %zu workgroup shapes' worth of strips\n", members, stacks.size());
     }
     return 0;
 }
@@ -324,7 +396,7 @@ int SearchRun::begin(uint64_t *slots_out)
 {
     if (!c->have_queries) return fail("swimm_hip_search: no queries set");
     if (c->groups.empty()) return fail("swimm_hip_search: no database chunk resident");
-    HIP_TRY(hipSetDevice(c->device));
+    CHECK_DEVICE(c);
     if (refresh_plans(c)) return 1;
     qn = qe - qb;
     dbg = getenv("SWIMM_HIP_DEBUG") != nullptr;
@@ -496,6 +568,9 @@ int SearchRun::plan_queries()
                 rotated[q] = choose_plan(c, main_mode, qm[q], false, true, &qps[q]) == 0;   // fails when no one-pass shape exists
                 if (!rotated[q] && batch_formed) { in_batch[q] = 1; if (choose_batch_shapes(c, main_mode, qm + q, 1, one_plan)) return 1; qps[q] = one_plan[0]; }   // ... then it stays in the batch
             }
+    c->batch_now = batch_formed;
+    if (build_stacks()) return 1;
+    c->batch_now = false;
     std::vector<BulkCols> rbulk;
     if (streaming && !batch_formed && ranges.size() > 1) {
         rqps.assign(ranges.size(), std::vector<QueryPlan>(qn));
@@ -503,6 +578,10 @@ int SearchRun::plan_queries()
         for (size_t ri = 0; ri < ranges.size(); ++ri) bulk_cols_of(c, ranges[ri], rbulk[ri]);
     }
     for (uint32_t q = 0; q < qn; ++q) {
+        if (stack_of[q] >= 0) {                            // the query runs as a member of a stack: the stack's shape, one pass
+            const Stack &st = stacks[stack_of[q]];
+            qps[q].T = st.T; qps[q].W = st.W; qps[q].passes = 1; qps[q].mpad = 0;
+        }
         if (!in_batch[q] && !rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;   // (a batch's shapes are chosen above)
         if (dbg)
             fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
@@ -519,6 +598,10 @@ int SearchRun::plan_queries()
         qps[q].mpad = std::max(qps[q].mpad, lane_rows);
         qps[q].prof_off = prof_elems;
         prof_elems += (size_t)kCodes * qps[q].mpad;
+    }
+    for (Stack &st : stacks) {                             // a stack's own profile: its members' rows, strip after strip
+        st.prof_off = prof_elems;
+        prof_elems += (size_t)kCodes * st.rows;
     }
     // Two or more multi-pass queries: their passes alternate between the two bulk streams (each with a boundary buffer
     // of its own), so that the end of every launch -- the last workgroups finishing alone -- is covered by a kernel of
@@ -540,6 +623,15 @@ int SearchRun::upload_profiles()
             for (uint32_t r = 0; r < qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + d];
         }
     }
+    for (const Stack &st : stacks)
+        for (size_t k = 0; k < st.q.size(); ++k) {
+            const uint32_t q = st.q[k];
+            const int8_t *qa = c->qcodes.data() + qdisp[q];
+            for (int d = 0; d < kCodes; ++d) {
+                int16_t *row = prof.data() + st.prof_off + (size_t)d * st.rows + (size_t)st.strip0[k] * st.T;
+                for (uint32_t r = 0; r < qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + d];
+            }
+        }
     c->last_plans.resize(c->qm.size());
     for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = in_batch[q] != 0; c->last_plans[qb + q] = qps[q]; }
     for (auto &rv : rqps)
@@ -676,24 +768,46 @@ int SearchRun::issue()
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->ev_query.push_back(e);
     }
-    std::map<std::pair<int, int>, std::vector<uint32_t>> batches;     // launch shape (T, W) -> queries whose bulk part runs group-resident
-    // the query table of the group-resident launches: per launch shape, the queries in ascending length (the kernel takes
-    // index nq - 1, the longest, first); the same for every range, so it travels once
+    // the query table of the group-resident launches: per launch shape, the stacks of short queries, then the queries in
+    // ascending length (the kernel takes index nq - 1, the longest, first); the same for every range, so it travels once
     std::map<std::pair<int, int>, size_t> qdesc_off;
-    if (c->batch_now) {
-        std::map<std::pair<int, int>, std::vector<uint32_t>> by_shape;
+    by_shape.clear();
+    {
+        for (size_t si = 0; si < stacks.size(); ++si)
+            if (stacks[si].resident) by_shape[std::make_pair(stacks[si].T, stacks[si].W)].push_back(Unit{(int)si, 0});
         for (uint32_t q = 0; q < qn; ++q)
-            if (qps[q].resident) by_shape[std::make_pair(qps[q].T, qps[q].W)].push_back(q);
+            if (qps[q].resident && stack_of[q] < 0) by_shape[std::make_pair(qps[q].T, qps[q].W)].push_back(Unit{-1, q});
         std::vector<QDesc> qd_host;
+        std::vector<uint32_t> wave_host;
+        for (Stack &st : stacks) {                          // every stack's waves: the score row of the member the wave belongs to
+            st.wave_tab = (uint32_t)wave_host.size();
+            for (int k = 0, mi = 0; k < st.W; ++k) {
+                while (mi + 1 < (int)st.q.size() && (uint32_t)k >= st.strip0[mi + 1]) ++mi;
+                if ((uint64_t)st.q[mi] * S > 0xFFFFFFFFull) return fail("stacked queries: score rows beyond 2^32 elements (lower score_mib)");
+                wave_host.push_back((uint32_t)((uint64_t)st.q[mi] * S));
+            }
+        }
         for (auto &kv : by_shape) {
             qdesc_off[kv.first] = qd_host.size();
-            for (uint32_t q : kv.second) {
-                if ((uint64_t)q * S > 0xFFFFFFFFull || qps[q].prof_off > 0xFFFFFFFFull) return fail("group-resident batch: score rows beyond 2^32 elements (lower score_mib)");
-                qd_host.push_back(QDesc{(uint32_t)qps[q].prof_off, qps[q].mpad, (uint32_t)qps[q].passes, (uint32_t)((uint64_t)q * S)});
+            for (const Unit &u : kv.second) {
+                QDesc d{};
+                if (u.stack >= 0) {
+                    const Stack &st = stacks[u.stack];
+                    if (st.prof_off > 0xFFFFFFFFull) return fail("group-resident batch: profiles beyond 2^32 elements");
+                    d.prof_off = (uint32_t)st.prof_off; d.prof_stride = st.rows; d.passes = 1; d.out_off = 0; d.seam_mask = st.seam_mask; d.wave_tab = st.wave_tab;
+                } else {
+                    const uint32_t q = u.q;
+                    if ((uint64_t)q * S > 0xFFFFFFFFull || qps[q].prof_off > 0xFFFFFFFFull) return fail("group-resident batch: score rows beyond 2^32 elements (lower score_mib)");
+                    d.prof_off = (uint32_t)qps[q].prof_off; d.prof_stride = qps[q].mpad; d.passes = (uint32_t)qps[q].passes; d.out_off = (uint32_t)((uint64_t)q * S);
+                    d.seam_mask = 0; d.wave_tab = kNoTab;
+                }
+                qd_host.push_back(d);
             }
         }
         HIP_TRY(c->d_qdesc.reserve(qd_host.size()));
-        if (list_copy(c, c->d_qdesc.p, qd_host.data(), qd_host.size() * sizeof(QDesc)) || list_sync(c)) return 1;
+        HIP_TRY(c->d_wave_out.reserve(wave_host.size()));
+        if (list_copy(c, c->d_qdesc.p, qd_host.data(), qd_host.size() * sizeof(QDesc)) ||
+            list_copy(c, c->d_wave_out.p, wave_host.data(), wave_host.size() * sizeof(uint32_t)) || list_sync(c)) return 1;
     }
     if (streaming)          // the first range's work lists need its geometry only: ready before its bytes are
         for (uint32_t q = 0; q < qn; ++q) { DbPlan *dp = nullptr; if (plan_of(0, q, &dp)) return 1; }
@@ -711,6 +825,7 @@ int SearchRun::issue()
         // the bulk kernels of the shorter queries instead of running alone at the end.
         for (uint32_t k = 0; k < qn; ++k) {
             const uint32_t q = qn - 1 - k;                 // queries arrive sorted by ascending length
+            if (stack_of[q] >= 0 || qps[q].resident) continue;     // its stack / its batch launch takes it, below
             DbPlan *dp = nullptr;
             if (plan_of(ri, q, &dp)) return 1;
             int32_t *row = c->d_scores.p + (size_t)q * S;
@@ -755,13 +870,7 @@ int SearchRun::issue()
             if (streaming && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
             // (the tail's first tier is the bulk's: binary16 pairs, unless that tier is switched off; the ladder below re-runs
             // what reaches 2048 in int16 -- rare, the chains are long but the scores are not)
-            if (!qps[q].resident && run_lane_passes(c, main_mode == Mode::F16 ? Mode::F16 : Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
-            if (qps[q].resident) {      // every group goes into the group-resident launch of its shape, below
-                if (dp->have_main) batches[std::make_pair(qps[q].T, qps[q].W)].push_back(q);
-                else HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
-                HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
-                continue;
-            }
+            if (run_lane_passes(c, main_mode == Mode::F16 ? Mode::F16 : Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
             if (dbg)
                 fprintf(stderr, "swimm_hip: query %u (%u rows, %d passes of %d x %d): bulk on %s, tail on %s\n", q, qm[q], qp_of(ri, q).passes, qp_of(ri, q).W, qp_of(ri, q).T,
                         bulk_stream == c->stream ? "stream A" : bulk_stream == c->stream_b ? "stream B" : "the tail stream",
@@ -772,22 +881,44 @@ int SearchRun::issue()
                 HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
             }
         }
+        // The stacks of short queries that run in rotation (no group-resident batch): one per-pass launch per stack, on
+        // the three streams in turn like the single short queries above.
+        for (size_t si = 0; si < stacks.size(); ++si) {
+            const Stack &stk = stacks[si];
+            if (stk.resident) continue;
+            QueryPlan sp{};
+            sp.T = stk.T; sp.W = stk.W; sp.passes = 1; sp.mpad = stk.rows; sp.prof_off = stk.prof_off; sp.mode = main_mode; sp.dynamic = true; sp.resident = false;
+            sp.stack = true; sp.seam_mask = stk.seam_mask; sp.wave_tab = stk.wave_tab;
+            DbPlan *dp = nullptr;
+            if (plan_for(ri, stk.T, stk.W, false, true, &dp)) return 1;
+            hipStream_t st = c->stream;
+            switch (one_pass_seen++ % 3) {
+            case 0: st = c->stream; break;
+            case 1: st = c->stream_b; break;
+            default: st = c->stream2; break;
+            }
+            if (dp->have_main && run_passes(c, main_mode, sp, dp->main, c->d_scores.p, st, false, c->d_bnd)) return 1;
+            if (ri + 1 == ranges.size())
+                for (uint32_t q : stk.q) { HIP_TRY(hipEventRecord(c->ev_query[2 * q], st)); HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], st)); }
+        }
         // Group-resident launches: ONE launch per launch shape for all the batch's queries of that shape -- the items are
         // (group, query) pairs, so even a small database gives every workgroup hundreds of them, the pipelines fill and
         // drain once per batch, and no pass waits for the slowest workgroup of the one before it.  Shapes alternate
         // between the two bulk streams.
-        if (!batches.empty()) {
+        {
             uint32_t bi = 0;
-            for (auto &kv : batches) {
-                std::sort(kv.second.begin(), kv.second.end());          // (the order of the query table)
+            for (auto &kv : by_shape) {
                 const size_t off = qdesc_off[kv.first];
                 const int T = kv.first.first, W = kv.first.second;
                 const uint32_t nqb = (uint32_t)kv.second.size();
                 DbPlan *dp = nullptr;
-                if (plan_of(ri, kv.second[0], &dp)) return 1;
+                if (plan_for(ri, T, W, true, true, &dp)) return 1;
                 uint64_t pass_sum = 0;
                 uint32_t max_p = 1;
-                for (uint32_t q : kv.second) { pass_sum += qps[q].passes; max_p = std::max<uint32_t>(max_p, qps[q].passes); }
+                for (const Unit &u : kv.second) {
+                    const uint32_t ps = u.stack >= 0 ? 1u : (uint32_t)qps[u.q].passes;
+                    pass_sum += ps; max_p = std::max<uint32_t>(max_p, ps);
+                }
                 // (a database that streams in: three ranges in flight, each on a stream and a boundary scratch of its own --
                 // no tail kernels beside group-resident launches, so the tail stream serves as the third)
                 // Which of the three: the one expected to be free first.  A launch lasts as long as its longest item's chain
@@ -807,11 +938,16 @@ int SearchRun::issue()
                 }
                 hipStream_t st = si == 0 ? c->stream : si == 1 ? c->stream_b : c->stream2;
                 DevBuf<uint2> &bnd = si == 0 ? c->d_bnd : si == 1 ? c->d_bnd_b : c->d_bnd_c;
-                if (run_resident_batch(c, main_mode, T, W, dp->main, c->d_qdesc.p + off, nqb, pass_sum, max_p, st, bnd)) return 1;
-                for (uint32_t q : kv.second) HIP_TRY(hipEventRecord(c->ev_query[2 * q], st));
+                if (dp->have_main && run_resident_batch(c, main_mode, T, W, dp->main, c->d_qdesc.p + off, nqb, pass_sum, max_p, st, bnd)) return 1;
+                for (const Unit &u : kv.second) {
+                    if (u.stack >= 0) {
+                        for (uint32_t q : stacks[u.stack].q) { HIP_TRY(hipEventRecord(c->ev_query[2 * q], st)); HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], st)); }
+                    } else {
+                        HIP_TRY(hipEventRecord(c->ev_query[2 * u.q], st)); HIP_TRY(hipEventRecord(c->ev_query[2 * u.q + 1], st));
+                    }
+                }
                 ++bi;
             }
-            batches.clear();
         }
         // the next range's work lists need its geometry only: build them now, while the GPU aligns this range and
         // before the host blocks in the next range's copies

@@ -30,11 +30,18 @@ struct Item {
 };
 
 // group-resident launches: one query of the batch the launch serves
+// A "query" of a launch may also be a STACK of short queries that share one workgroup: query A in the first strips (waves),
+// query B in the next ones, ... each padded to whole strips, one pass.  A wave that starts a member takes a zero top
+// boundary instead of its upper neighbour's bottom row (seam), and every wave's best goes to the score row of ITS member.
+constexpr uint32_t kNoTab = 0xFFFFFFFFu;
 struct QDesc {
-    uint32_t prof_off;      // first element of the query's profile in PipeParams::prof
+    uint32_t prof_off;      // first element of the query's (or the stack's concatenated) profile in PipeParams::prof
     uint32_t prof_stride;   // rows allocated per residue code
-    uint32_t passes;        // ceil(rows / (W * T))
+    uint32_t passes;        // ceil(rows / (W * T)); a stack has one
     uint32_t out_off;       // first element of the query's score row in PipeParams::out
+    uint32_t seam_mask;     // stack: bit k = wave k starts a member query
+    uint32_t wave_tab;      // stack: PipeParams::wave_out[wave_tab + k] = first element of wave k's member's score row; kNoTab = a plain query
+    uint32_t pad_[2];
 };
 
 struct PipeParams {
@@ -54,6 +61,10 @@ struct PipeParams {
     uint32_t n_queries;         // (qdesc != nullptr selects the group-resident kernel: every workgroup takes a group through all
                                 // the passes of an item's query back to back)
     uint32_t bnd_wg_cols;       // group-resident launches: bnd holds this many columns per workgroup, touched by it alone
+    const uint32_t *wave_out;   // stacks of short queries: per (stack, wave) the score row of the wave's member (group-resident launches: indexed
+                                // through QDesc::wave_tab; a per-pass launch: non-null selects the stack below)
+    uint32_t seam_mask;         // per-pass launch of ONE stack: its seam bits ...
+    uint32_t wave_tab;          // ... and its first entry in wave_out
     int32_t *out;               // packed mode: score row of this query; int32 mode: out32
     int goe, ge;                // open+extend, extend
     uint32_t *err;              // watchdog word shared with the lane kernel

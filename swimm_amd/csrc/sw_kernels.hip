@@ -181,14 +181,18 @@ __device__ __forceinline__ Item load_item(const Item *items, uint32_t idx)
     return it;
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-static_assert(sizeof(QDesc) == 16, "QDesc is loaded as four dwords");
+static_assert(sizeof(QDesc) == 32, "QDesc is loaded as eight dwords");
 __device__ __forceinline__ QDesc load_qdesc(const QDesc *q, uint32_t idx)
 {
-    const u32x4 r = *(const __attribute__((address_space(4))) u32x4 *)(uintptr_t)(q + idx);
+    const u32x8 r = *(const __attribute__((address_space(4))) u32x8 *)(uintptr_t)(q + idx);
     QDesc d;
-    d.prof_off = r[0]; d.prof_stride = r[1]; d.passes = r[2]; d.out_off = r[3];
+    d.prof_off = r[0]; d.prof_stride = r[1]; d.passes = r[2]; d.out_off = r[3]; d.seam_mask = r[4]; d.wave_tab = r[5];
     return d;
+}
+// one entry of a read-only table, wave-uniform index: a scalar load
+__device__ __forceinline__ uint32_t load_u32_uniform(const uint32_t *t, uint32_t idx)
+{
+    return *(const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(t + idx);
 }
 
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t x)
@@ -336,6 +340,12 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
     uint32_t passes = 1, cur_q = 0, q_stride = RES ? 0 : p.prof_stride;
     const int16_t *q_prof = p.prof;
     int32_t *q_out = p.out;
+    // a stack of short queries shares the workgroup: this wave starts a member (zero top boundary), its best goes to its member's row
+    bool seam = false;
+    if (!RES && p.wave_out != nullptr) {
+        seam = (p.seam_mask >> k) & 1u;
+        q_out = p.out + load_u32_uniform(p.wave_out, p.wave_tab + (uint32_t)k);
+    }
     int staged_win = -1;                   // RES: which (query << 16 | pass) window this wave's strip of the LDS profile holds
     // RES: the strip's profile rows of the NEXT window are requested during the last chunk of the current item-pass, straight
     // into a per-wave landing area in LDS (global_load_lds: no registers), so that the switch itself is a handful of LDS
@@ -404,6 +414,11 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
                     cur_q = nq - 1 - (vi - gi * nq);
                     const QDesc qd = load_qdesc(p.qdesc, cur_q);
                     passes = qd.passes; q_prof = p.prof + qd.prof_off; q_stride = qd.prof_stride; q_out = p.out + qd.out_off;
+                    seam = false;
+                    if (qd.wave_tab != kNoTab) {
+                        seam = (qd.seam_mask >> k) & 1u;
+                        q_out = p.out + load_u32_uniform(p.wave_out, qd.wave_tab + (uint32_t)k);
+                    }
                 }
                 // (wave 0 may read a column's boundary two steps after the last wave stored it at the earliest: the storing wave
                 // drains its stores at the top of its next step, below)
@@ -455,8 +470,8 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
             // top boundary of the strip for these columns: H of the row above, F entering row 0
             uint2 bin[C];
             const bool first_pass = RES ? pass == 0 : (bool)p.first_pass, last_pass = RES ? pass + 1 == passes : (bool)p.last_pass;
-            if (k == 0) {
-                if (first_pass) {
+            if (k == 0 || seam) {
+                if (first_pass || seam) {
 #pragma unroll
                     for (int jj = 0; jj < C; ++jj) bin[jj] = make_uint2(0u, 0u);
                 } else {

@@ -10,6 +10,7 @@
 #include "swimm_impl.h"
 
 thread_local std::string swimm_impl::g_err;
+thread_local int swimm_impl::g_cur_vdevice = -1;
 
 extern "C" {
 
@@ -43,6 +44,7 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= virtual_gpus(n)) return fail("swimm_hip_create: device %d not in [0,%d)", device, virtual_gpus(n));
+    const int vdevice = device;
     device %= std::max(n, 1);
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -51,6 +53,8 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
         return fail("swimm_hip_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
     swimm_hip_ctx *c = new swimm_hip_ctx();
     c->device = device;
+    c->vdevice = vdevice;
+    g_cur_vdevice = vdevice;
     c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream_b) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
@@ -88,10 +92,10 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
 void swimm_hip_destroy(swimm_hip_ctx *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    (void)ctx_enter(c);
     delete c->up; c->up = nullptr;
     swimm_hip_clear_db(c);
-    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_qdesc.release();
+    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_qdesc.release(); c->d_wave_out.release();
     if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = c->pin_used = 0; }
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_a.release(); c->tail_scratch_b.release(); c->tail_scratch_t[0].release(); c->tail_scratch_t[1].release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -179,7 +183,7 @@ int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint
     for (uint32_t g = 0; g < group_count; ++g)
         if ((uint64_t)b_disp[g] + (uint64_t)n[g] * vl > vD)
             return fail("swimm_hip_add_chunk: group %u (disp %u, n %u) runs past vD=%llu", g, b_disp[g], n[g], (unsigned long long)vD);
-    HIP_TRY(hipSetDevice(c->device));
+    if (ctx_enter(c)) return 1;
     // A chunk that will stream in (lazy_upload) is recorded in pieces of about upload_piece_kib (default 96 MiB, the
     // reference's chunk size): a caller that hands over its database as one 0.6 GB buffer still gets ranges that overlap
     // copy and alignment.  (Finer pieces do not pay: with 32 MiB the first kernel starts 1.5 ms sooner, but the search
@@ -243,7 +247,7 @@ static int add_sequences_piece(swimm_hip_ctx *c, const uint16_t *lengths, const 
     uint64_t total = 0;
     for (uint64_t i = 0; i < n_seq; ++i) { rec.off[i] = (uint32_t)total; total += lengths[i]; if (total > 0xFFFFFFF0ull) return fail("swimm_hip_add_sequences: slab larger than 4 GiB"); }
     rec.off[n_seq] = (uint32_t)total;
-    HIP_TRY(hipSetDevice(c->device));
+    if (ctx_enter(c)) return 1;
     rec.h_codes = codes; rec.code_bytes = total;
     rec.n_groups = (uint32_t)((n_seq + kGroupSeqs - 1) / kGroupSeqs);
     rec.goff.resize(rec.n_groups);
@@ -265,7 +269,7 @@ static int add_sequences_piece(swimm_hip_ctx *c, const uint16_t *lengths, const 
 int swimm_hip_clear_db(swimm_hip_ctx *c)
 {
     if (!c) return fail("swimm_hip_clear_db: NULL ctx");
-    (void)hipSetDevice(c->device);
+    if (ctx_enter(c)) return 1;
     (void)hipDeviceSynchronize();                 // nothing in flight may still read the chunks
     for (auto &ch : c->chunks) { (void)hipFree(ch.d_tiled); (void)hipFree(ch.d_len); if (ch.ready) (void)hipEventDestroy(ch.ready); }
     c->chunks.clear(); c->groups.clear(); c->group_col_off.clear(); c->seq_len.clear();
@@ -289,6 +293,7 @@ static void reset_stats(swimm_hip_ctx *c) { c->kernel_ms = 0; c->cells = 0; c->p
 int swimm_hip_search(swimm_hip_ctx *c, int32_t *scores, uint64_t score_stride, double *work_time)
 {
     if (!c || !scores) return fail("swimm_hip_search: NULL argument");
+    if (ctx_enter(c)) return 1;
     const double t0 = now_s();
     reset_stats(c);
     const uint32_t qtotal = (uint32_t)c->qm.size(), B = query_batch(c);
@@ -317,6 +322,7 @@ int swimm_hip_search_topr(swimm_hip_ctx *c, uint32_t r, uint64_t n_valid, int32_
 {
     if (!c || !top_scores || !top_index) return fail("swimm_hip_search_topr: NULL argument");
     if (r == 0) return fail("swimm_hip_search_topr: r must be > 0");
+    if (ctx_enter(c)) return 1;
     const double t0 = now_s();
     reset_stats(c);
     const uint32_t qtotal = (uint32_t)c->qm.size(), B = query_batch(c);
@@ -442,6 +448,7 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *c, uint32_t q, char *buf, size_t b
 int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail("swimm_hip_set_option: NULL argument");
+    if (ctx_enter(c)) return 1;          // (some options release the cached work lists)
     if (!strcmp(key, "rows_per_wave")) {
         if (value != 0 && (value < 8 || value > 36 || value % 4)) return fail("rows_per_wave must be 0 (auto) or a multiple of 4 in 8..36");
         c->opt_T = value;
@@ -469,6 +476,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "rotate")) {
         c->opt_rotate = value != 0;
+    } else if (!strcmp(key, "stack")) {
+        c->opt_stack = value != 0;
     } else if (!strcmp(key, "lane_rows")) {
         c->opt_lane_rows = value != 0;
     } else if (!strcmp(key, "lane_room")) {

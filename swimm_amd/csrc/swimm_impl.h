@@ -135,7 +135,11 @@ struct ChunkRec {
     hipEvent_t ready = nullptr; // recorded on the upload stream behind the chunk's (re-)tile kernel
 };
 
-struct QueryPlan { int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true, resident = false; };
+struct QueryPlan {
+    int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true, resident = false;
+    bool stack = false;                 // the "query" is a stack of short queries sharing one workgroup (QDesc in sw_kernels.h) ...
+    uint32_t seam_mask = 0, wave_tab = 0;   // ... with these seams and this first entry in d_wave_out
+};
 
 
 struct Range { uint32_t g0 = 0, g1 = 0; uint64_t cols = 0; };
@@ -146,7 +150,8 @@ struct WorkUnit { uint32_t group, half, out_slot; uint32_t ncols; uint64_t bnd_o
 using namespace swimm_impl;
 
 struct swimm_hip_ctx {
-    int device = 0;
+    int device = 0;                     // physical device
+    int vdevice = 0;                    // the device number the caller asked for (differs under the test hook SWIMM_HIP_VIRTUAL_GPUS)
     hipStream_t stream = nullptr;
     hipStream_t stream_b = nullptr;     // second bulk stream: multi-pass queries run the two halves of the group list side by side
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -177,6 +182,8 @@ struct swimm_hip_ctx {
     std::vector<uint8_t> stream_tail;   // streaming search: the tail flags of the whole database (pick_tail)
     bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
     DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
+    DevBuf<uint32_t> d_wave_out;        // stacks of short queries: per (stack, wave) the first element of the wave's member's score row
+    int opt_stack = 1;                  // 1: short one-pass queries of a batch share workgroups (several queries stacked along the strips)
     int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
     std::vector<hipEvent_t> launch_ev;  // pairs (before, after), grown on demand
     size_t launch_ev_used = 0;
@@ -241,6 +248,26 @@ struct swimm_hip_ctx {
 
 namespace swimm_impl {
 
+// Device discipline.  A context belongs to one device and every HIP call made for it -- allocations, copies, launches,
+// events -- needs that device to be the calling thread's current one.  Every entry point of the C-ABI (and the uploader
+// thread) starts with ctx_enter(); the internal functions that issue HIP calls start with CHECK_DEVICE, which compares a
+// thread-local record of the last context entered with the context at hand.  With the test hook SWIMM_HIP_VIRTUAL_GPUS all
+// "devices" are one physical GPU and a missing hipSetDevice would go unnoticed by HIP itself; the record is kept per
+// VIRTUAL device, so it shows even there (tests/test_gpu_parity.py::test_two_contexts_interleaved_on_one_thread).
+extern thread_local int g_cur_vdevice;
+inline int ctx_enter(swimm_hip_ctx *c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    g_cur_vdevice = c->vdevice;
+    return 0;
+}
+#define CHECK_DEVICE(c)                                                                                            \
+    do {                                                                                                           \
+        if (swimm_impl::g_cur_vdevice != (c)->vdevice)                                                             \
+            return fail("internal: %s runs for device %d but the calling thread last entered device %d (%s:%d)", __func__, (c)->vdevice, \
+                        swimm_impl::g_cur_vdevice, __FILE__, __LINE__);                                            \
+    } while (0)
+
 int upload_chunk(swimm_hip_ctx *c, ChunkRec &r);
 
 // The uploader of a database that streams in (option "lazy_upload"): a thread of its own, one per context, started when
@@ -269,7 +296,7 @@ struct Uploader {
     }
     void run()
     {
-        bool dev_ok = hipSetDevice(c->device) == hipSuccess;
+        bool dev_ok = ctx_enter(c) == 0;
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
             cv.wait(lk, [&]() { return have_job || quit; });
@@ -329,6 +356,7 @@ void bulk_cols_of(const swimm_hip_ctx *c, const Range &rg, BulkCols &b);
 double plan_imbalance(swimm_hip_ctx *c, int n_wg);
 int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bool overlapped, QueryPlan *out,
                 const Range *rg = nullptr, BulkCols *rb = nullptr);
+double shape_gcups(int T, int W);      // measured rate of a launch shape of the f16-tier pipeline kernel (GCUPS of padded cells)
 uint64_t prof_elems_bound(const uint16_t *qm, uint32_t qn);
 int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_t qn, std::vector<QueryPlan> &qps);
 int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, Plan &pl);

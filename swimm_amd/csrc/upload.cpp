@@ -15,6 +15,7 @@ int refresh_plans(swimm_hip_ctx *c)
 // Registers a chunk's device groups (geometry only: nothing is copied here).
 int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> &lens_or_empty)
 {
+    CHECK_DEVICE(c);
     const uint32_t dev_groups = rec.n_groups;
     uint64_t bytes = 0;
     for (uint32_t g = 0; g < dev_groups; ++g) { rec.goff[g] = bytes; bytes += (uint64_t)rec.gcols[g] * kGroupSeqs; }
@@ -56,6 +57,7 @@ int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> 
 int upload_chunk(swimm_hip_ctx *c, ChunkRec &r)
 {
     if (r.uploaded) return 0;
+    CHECK_DEVICE(c);
     hipStream_t s = c->stream_up;
     const uint32_t dev_groups = r.n_groups;
     uint32_t max_cols = 0;
@@ -106,6 +108,7 @@ int ensure_uploader(swimm_hip_ctx *c)
 // (lane-systolic work lists, promotion re-runs), not inside add_chunk
 int sync_lengths(swimm_hip_ctx *c)
 {
+    CHECK_DEVICE(c);
     bool any = false;
     for (ChunkRec &r : c->chunks) {
         if (r.lens_known || !r.uploaded) continue;

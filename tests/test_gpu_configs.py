@@ -109,6 +109,7 @@ def test_c5_envnr_pam250_eight_way_shard(monkeypatch):
     owner = sharding.assign_chunks([c["vD"] for c in chunks.chunks], G)
     q = {"a": w["a"], "m": w["m"], "disp": w["disp"]}
     got = np.full((len(w["m"]), chunks.vc * 128), -7, dtype=np.int32)
+    got_default = np.full((len(w["m"]), chunks.vc * 128), -7, dtype=np.int32)
     lists_s, lists_i = [], []
     for d in range(G):
         mine = [c for i, c in enumerate(chunks.chunks) if owner[i] == d]
@@ -139,7 +140,14 @@ def test_c5_envnr_pam250_eight_way_shard(monkeypatch):
             ts, ti, _ = s.search_topr(20, w["n"])
         lists_s.append(ts)
         lists_i.append(ti)
+        # ... and the same shard with the planner's own choices (no workgroup cap, its own tail rule, batch or per-pass
+        # launches as it sees fit): what a real 8-GPU run of this database executes on device d
+        with hip_backend.HipSearcher(d) as s:
+            s.set_queries(q["a"], q["m"], q["disp"], sm, 10, 2)
+            _load(s, mine)
+            s.search(chunks.vc * 128, out=got_default)
     assert not (got[:, :w["n"]] == -7).any()                   # every sequence was resident on exactly one device
+    assert np.array_equal(got_default[:, :w["n"]], got[:, :w["n"]])
     want, idx = oracle_matrix(w)
     _check_matrix(got[:, :w["n"]], want, idx, "c5 (8-way shard)")
     for k in range(len(w["m"])):                               # host merge of the 8 per-device lists == the reference's listing

@@ -175,3 +175,59 @@ def test_random_session_on_one_context(seed):
                     assert np.array_equal(ts[k][:len(os_)], os_) and np.array_equal(ti[k][:len(oi)], oi), tag + f" top-{r} of query {k}"
     for c in keep + ([chunks] if chunks is not None else []):
         c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWIMM_FUZZ_SHORT", "14"))))
+def test_short_query_batches_share_workgroups(seed):
+    """Batches of 8 to 240 SHORT queries (1 to 90 rows, a few longer ones among them): queries of up to 72 rows are stacked
+    two to four to a workgroup (a zero boundary at every seam, one score row per member) -- in group-resident batch launches
+    on a database that is small beside the chip, in rotation over three streams on a larger one -- and every member's
+    whole score row must equal the checker's (a member of up to 72 rows cannot leave the binary16 range: 72 x 17 < 2048)."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([300, 1500, 6000, 30000, 120000]))
+    L = np.clip(rng.lognormal(np.log(float(rng.choice([40, 150, 300]))), 0.6, n), 1, 2500).astype(np.int64)
+    if rng.random() < 0.3:
+        L[rng.integers(0, n)] = int(rng.integers(2000, 8000))
+    L = np.sort(L).astype(np.uint16)
+    total = int(L.astype(np.int64).sum())
+    codes = rng.integers(0, 23, total).astype(np.int8)
+    offs = np.concatenate([[0], np.cumsum(L.astype(np.int64))])
+    nq = int(rng.choice([8, 9, 40, 100, 240]))
+    qlens = rng.integers(1, 91, nq)
+    for _ in range(int(rng.integers(0, 3))):
+        qlens[rng.integers(0, nq)] = int(rng.integers(100, 900))
+    qlens = np.sort(qlens)
+    queries = []
+    for ql in qlens:
+        q = rng.integers(0, 23, int(ql)).astype(np.int8)
+        if rng.random() < 0.5:
+            i = int(rng.integers(0, n))
+            k = int(min(L[i], ql))
+            q[:k] = codes[offs[i]:offs[i] + k]
+        queries.append(q)
+    queries.sort(key=len)
+    m = np.array([len(q) for q in queries], np.uint16)
+    disp = np.concatenate([[0], np.cumsum(m.astype(np.int64))]).astype(np.uint32)
+    w = {"lengths": L, "codes": codes, "offs": offs, "n": n, "residues": total, "a": np.concatenate(queries), "m": m, "disp": disp,
+         "query_residues": int(m.astype(np.int64).sum()), "matrix": "blosum62" if seed % 2 == 0 else str(rng.choice(MATRICES))}
+    go, ge = (10, 2) if seed % 2 == 0 else (int(rng.integers(0, 21)), int(rng.integers(0, 6)))
+    opts = {}
+    for key, vals in [("resident", [0, 1]), ("rotate", [0]), ("f16", [0]), ("tail_mode", [2]), ("score_mib", [1]), ("wg_limit", [8]), ("force_i32", [1])]:
+        if rng.random() < 0.2:
+            opts[key] = int(rng.choice(vals))
+    sm = submat.table(w["matrix"])
+    lazy = bool(rng.random() < 0.3)
+    with hip_backend.HipSearcher(0) as s:
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.set_option("lazy_upload", int(lazy))
+        s.set_queries(w["a"], m, disp, sm, go, ge)
+        s.add_sequences(L, codes, first_seq=0)
+        stride = (n + 127) // 128 * 128
+        got, _ = s.search(stride)
+        s.set_option("stack", 0)
+        plain, _ = s.search(stride)
+    want, idx = oracle_matrix(w, go=go, ge=ge)
+    tag = f"short-query seed {seed}: {n} sequences, {nq} queries {m.tolist()[:12]}..., {w['matrix']} {go}/{ge}, lazy {lazy}, options {opts}"
+    assert np.array_equal(plain[:, :n], want), tag + " (stack=0)"
+    assert np.array_equal(got[:, :n], want), tag

@@ -247,3 +247,48 @@ def test_streaming_upload_c2_shape():
     for i in list(np.random.default_rng(3).integers(0, shard["n"], 60)) + [int(np.argmax(res[0][0, :shard["n"]]))]:
         assert res[0][0, i] == port.pair_score(qa, shard["codes"][offs[i]:offs[i + 1]], sm, 10, 2), i
     chunks.close()
+
+
+def test_two_contexts_interleaved_on_one_thread(tmp_path, golden, monkeypatch):
+    """Two live contexts on two (virtual) devices driven by ONE host thread in interleaved order -- create A, create B,
+    chunks into A, chunks into B, search B, search A, top-r A, more chunks into B, search B: every entry point has to make
+    its own context's device current again (the library records the device last entered per thread and refuses a HIP call
+    issued for another context: a missing switch is an error here even though both devices are one physical GPU)."""
+    monkeypatch.setenv("SWIMM_HIP_VIRTUAL_GPUS", "2")
+    q, pp, chunked = golden_inputs(tmp_path, golden, vl=128, max_chunk=30000)
+    N = golden["search"]["n_sequences"]
+    want = load_npy("scores_blosum62_g10_e2.npy")
+    sm = matrix("blosum62")
+    chunks = chunked["chunks"]
+    firsts = np.concatenate([[0], np.cumsum([c["count"] for c in chunks])])
+    half = len(chunks) // 2
+    assert half >= 1
+    A, B = hip_backend.HipSearcher(0), hip_backend.HipSearcher(1)
+    try:
+        A.set_queries(q["a"], q["m"], q["disp"], sm, 10, 2)
+        B.set_option("lazy_upload", 1)                   # B streams its chunks in with its own uploader thread
+        B.set_queries(q["a"], q["m"], q["disp"], sm, 10, 2)
+        for k in range(half):
+            A.add_chunk(chunks[k]["b"], chunks[k]["n"], chunks[k]["disp"], 128, int(firsts[k]))
+        for k in range(half, len(chunks)):
+            B.add_chunk(chunks[k]["b"], chunks[k]["n"], chunks[k]["disp"], 128, int(firsts[k]))
+        stride = int(firsts[-1]) * 128
+        got = np.full((len(q["m"]), stride), -3, np.int32)
+        B.search(stride, out=got)
+        A.search(stride, out=got)
+        ts, ti, _ = A.search_topr(5, N)
+        assert np.array_equal(got[:, :N], want)
+        # A's device is current now; B gets the first half as well and is searched again (all chunks resident on B)
+        for k in range(half):
+            B.add_chunk(chunks[k]["b"], chunks[k]["n"], chunks[k]["disp"], 128, int(firsts[k]))
+        B.set_option("tail_mode", 1)
+        got_b = np.full((len(q["m"]), stride), -3, np.int32)
+        B.search(stride, out=got_b)
+        A.clear_db()
+        assert np.array_equal(got_b[:, :N], want)
+        nA = int(firsts[half]) * 128
+        for k in range(len(q["m"])):
+            os_, oi = port.topr(want[k, :min(N, nA)], 5)
+            assert np.array_equal(ts[k], os_) and np.array_equal(ti[k], oi), k
+    finally:
+        A.close(); B.close()

@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 "$@" > $OUT/kt.log 2>&1
 echo "kt rc=$?"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -o pmc -- python3 "$@" > $OUT/pmc1.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc1 -o pmc -- python3 "$@" > $OUT/pmc1.log 2>&1
 echo "pmc1 rc=$?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -o pmc -- python3 "$@" > $OUT/pmc3.log 2>&1
 echo "pmc3 rc=$?"

@@ -136,6 +136,10 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    touches; no launch boundary).  -1 = default: formed when the call has two or more
  *                    queries (or streams its database in) and the database is small beside the chip; 0 = never: one launch
  *                    per pass of every query ("split", "bnd_mib" apply); 1 = always, every query joins
+ *   "tall"           -1 = default: a batch of queries against a database whose launches per pass would each be bound by its longest
+ *                    group's serial chain (few groups per CU) runs as ONE group-resident launch of tall workgroups (12 waves x 24
+ *                    rows, one per CU, the lane-systolic tail beside it) when that is estimated to be faster; 0 = never; 1 = whenever
+ *                    the 4-wave batch is not formed
  *   "stack"          1 = default: short queries (up to 72 rows) of a batch share workgroups -- two to four of them stacked along the
  *                    strips of one 4-wave workgroup, each with its own score row -- instead of padding each to a launch
  *                    shape of its own; 0 = every query its own workgroups

@@ -39,6 +39,13 @@ static int do_preprocess(const swimm_options *o)
     printf("Database size:\t\t\t%ld sequences (%ld residues) \n", (long)n, (long)d);
     printf("Preprocessed database name:\t%s\n", o->output_filename);
     printf("Preprocessing time:\t\t%lf seconds\n\n", swimm_wtime() - tick);
+    if (getenv("SWIMM_DEBUG")) {          /* peak resident memory of this process image (VmHWM), for tools/preprocess_scale.py */
+        FILE *st = fopen("/proc/self/status", "r");
+        char line[256];
+        while (st && fgets(line, sizeof line, st))
+            if (strncmp(line, "VmHWM:", 6) == 0 || strncmp(line, "RssAnon:", 8) == 0) fprintf(stderr, "swimm: %s", line);
+        if (st) fclose(st);
+    }
     return 0;
 }
 

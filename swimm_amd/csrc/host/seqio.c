@@ -181,70 +181,166 @@ static int check_lengths(const swimm_fasta *f, const char *what)
     return SWIMM_OK;
 }
 
+/* preprocess_db (sequences.c:4-220) at the scale SURVEY 8(f2) names: the reference walks the FASTA three times with fgets
+ * and mallocs every sequence and every title (sequences.c:28-50,55-58,64-80,88-91,102-119); here the file is mapped and
+ * walked ONCE, front to back: titles go into one arena, residues -- recoded on the way -- into another, both reserved as
+ * address space and touched only as far as they fill, and the pages of the file are handed back as the walk leaves them
+ * behind.  Peak memory is therefore the size of the output (.seq + .desc) plus 32 bytes per record, whatever the size of
+ * the input (round 2 held the file and a compacted copy: twice the FASTA).  Same bytes out: stable counting sort by length. */
+typedef struct { uint64_t *title_off, *seq_off; uint32_t *title_len, *len; uint64_t n, cap; } rec_index;
+
+static int rec_push(rec_index *x, uint64_t toff, uint32_t tlen, uint64_t soff)
+{
+    if (x->n == x->cap) {
+        const uint64_t cap = x->cap ? x->cap * 2 : (1u << 16);
+        uint64_t *a = (uint64_t *)realloc(x->title_off, cap * sizeof(uint64_t));
+        if (a) x->title_off = a;
+        uint64_t *b = (uint64_t *)realloc(x->seq_off, cap * sizeof(uint64_t));
+        if (b) x->seq_off = b;
+        uint32_t *c = (uint32_t *)realloc(x->title_len, cap * sizeof(uint32_t));
+        if (c) x->title_len = c;
+        uint32_t *d = (uint32_t *)realloc(x->len, cap * sizeof(uint32_t));
+        if (d) x->len = d;
+        if (!a || !b || !c || !d) return 1;
+        x->cap = cap;
+    }
+    x->title_off[x->n] = toff; x->title_len[x->n] = tlen; x->seq_off[x->n] = soff; x->len[x->n] = 0;
+    x->n++;
+    return 0;
+}
+
 int swimm_preprocess_db(const char *fasta_path, const char *out_prefix, uint64_t *n_sequences, uint64_t *n_residues)
 {
-    swimm_fasta f;
-    int rc = swimm_fasta_read(fasta_path, &f);
-    if (rc) return rc;
-    if (f.count == 0) { swimm_fasta_free(&f); return FAIL(SWIMM_E_FORMAT, "SWIMM: '%s' holds no FASTA record.", fasta_path); }
-    if ((rc = check_lengths(&f, "database"))) { swimm_fasta_free(&f); return rc; }
-    uint64_t *order = stable_length_order(f.lengths, f.count);
-    if (!order) { swimm_fasta_free(&f); return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); }
-    char name[4096];
-    size_t max_title = 0;
-    /* .desc : title lines (with '>') in sorted order, sequences.c:128-141 */
-    snprintf(name, sizeof name, "%s.desc", out_prefix);
-    FILE *fd = fopen(name, "wb");
-    if (!fd) { free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening sequence header file."); }
-    for (uint64_t i = 0; i < f.count; ++i) {
-        const char *t = f.titles[order[i]];
-        size_t tl = strlen(t);
-        if (tl > max_title) max_title = tl;
-        fwrite(t, 1, tl, fd);
-        fputc('\n', fd);
-    }
-    fclose(fd);
-    /* .info : "%ld %ld %d", no newline; max title = longest line incl. '>' + newline + 1 (sequences.c:36,187) */
-    snprintf(name, sizeof name, "%s.info", out_prefix);
-    FILE *fi = fopen(name, "wb");
-    if (!fi) { free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening info file."); }
-    fprintf(fi, "%ld %ld %d", (long)f.count, (long)f.residues, (int)(max_title + 2));
-    fclose(fi);
-    /* .seq : uint16 lengths, then recoded residues, both in sorted order (sequences.c:201-205) */
-    snprintf(name, sizeof name, "%s.seq", out_prefix);
-    FILE *fs = fopen(name, "wb");
-    if (!fs) { free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening sequence file."); }
-    uint16_t *l16 = (uint16_t *)malloc(f.count * sizeof(uint16_t));
-    if (!l16) { fclose(fs); free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); }
-    for (uint64_t i = 0; i < f.count; ++i) l16[i] = (uint16_t)f.lengths[order[i]];
-    fwrite(l16, sizeof(uint16_t), f.count, fs);
-    free(l16);
-    {   /* gather the sorted, recoded residues and write them in large blocks */
-        const size_t blk = (size_t)64 << 20;
-        char *out = (char *)malloc(blk);
-        if (!out) { fclose(fs); free(order); swimm_fasta_free(&f); return FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); }
-        size_t fill = 0;
-        for (uint64_t i = 0; i < f.count; ++i) {
-            uint64_t s = order[i];
-            size_t L = f.lengths[s], done = 0;
-            while (done < L) {
-                size_t n = L - done < blk - fill ? L - done : blk - fill;
-                memcpy(out + fill, f.seqs[s] + done, n);
-                fill += n; done += n;
-                if (fill == blk) { swimm_recode(out, fill); fwrite(out, 1, fill, fs); fill = 0; }
+    init_codes();
+    int fdin = open(fasta_path, O_RDONLY);
+    if (fdin < 0) return FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening input sequence file '%s'.", fasta_path);
+    struct stat sb;
+    if (fstat(fdin, &sb) != 0) { close(fdin); return FAIL(SWIMM_E_FILE, "SWIMM: cannot stat '%s'.", fasta_path); }
+    const size_t len = (size_t)sb.st_size;
+    if (len == 0) { close(fdin); return FAIL(SWIMM_E_FORMAT, "SWIMM: '%s' holds no FASTA record.", fasta_path); }
+    const char *buf = (const char *)mmap(NULL, len, PROT_READ, MAP_PRIVATE, fdin, 0);
+    close(fdin);
+    if (buf == MAP_FAILED) return FAIL(SWIMM_E_FILE, "SWIMM: cannot map '%s'.", fasta_path);
+    (void)madvise((void *)buf, len, MADV_SEQUENTIAL);
+    /* the two arenas: address space for the worst case (everything residues / everything titles), memory as they fill */
+    char *res = (char *)mmap(NULL, len + 1, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    char *tit = (char *)mmap(NULL, len + 1, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    rec_index x = {NULL, NULL, NULL, NULL, 0, 0};
+    int rc = SWIMM_OK;
+    uint64_t *order = NULL;
+    FILE *fd = NULL, *fs = NULL;
+    char *out = NULL;
+    uint16_t *l16 = NULL;
+    if (res == MAP_FAILED || tit == MAP_FAILED) { rc = FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory for sequences."); goto done; }
+    {
+        uint64_t w = 0, tw = 0;
+        int in_record = 0;
+        const size_t page = 4096, drop_every = (size_t)64 << 20;
+        size_t dropped = 0;
+        for (size_t i = 0; i < len;) {
+            const char *nl = (const char *)memchr(buf + i, '\n', len - i);
+            const size_t e = nl ? (size_t)(nl - buf) : len;         /* (the last line may lack its newline) */
+            if (buf[i] == '>') {
+                size_t te = e;
+                while (te > i && buf[te - 1] == '\r') te--;
+                if (rec_push(&x, tw, (uint32_t)(te - i), w)) { rc = FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory for sequences."); goto done; }
+                memcpy(tit + tw, buf + i, te - i);
+                tw += te - i;
+                in_record = 1;
+            } else if (in_record) {
+                size_t le = e;
+                while (le > i && (buf[le - 1] == '\r' || buf[le - 1] == ' ' || buf[le - 1] == '\t')) le--;
+                const size_t n = le - i;
+                uint64_t w0 = w;
+                if (n && !memchr(buf + i, ' ', n) && !memchr(buf + i, '\t', n)) {   /* the usual case: one memcpy per line */
+                    memcpy(res + w, buf + i, n);
+                    w += n;
+                } else {
+                    for (size_t j = i; j < le; ++j) {
+                        const unsigned char ch = (unsigned char)buf[j];
+                        if (ch == ' ' || ch == '\t' || ch == '\r') continue;
+                        res[w++] = (char)ch;
+                    }
+                }
+                for (uint64_t k = w0; k < w; ++k) res[k] = g_code[(unsigned char)res[k]];    /* sequences.c:164-175, while the line is in cache */
+                const uint64_t L = (uint64_t)x.len[x.n - 1] + (w - w0);
+                if (L > 65535) {
+                    rc = FAIL(SWIMM_E_FORMAT, "SWIMM: database sequence %llu ('%.60s') has more than 65535 residues; the format stores lengths in 16 bits.",
+                              (unsigned long long)(x.n - 1), tit + x.title_off[x.n - 1]);
+                    goto done;
+                }
+                x.len[x.n - 1] = (uint32_t)L;
+            }
+            i = e + 1;
+            if (i - dropped >= drop_every) {                           /* the walk is done with these pages of the file */
+                const size_t upto = i / page * page;
+                (void)madvise((void *)(buf + dropped), upto - dropped, MADV_DONTNEED);
+                dropped = upto;
             }
         }
-        if (fill) { swimm_recode(out, fill); fwrite(out, 1, fill, fs); }
-        free(out);
+        if (x.n == 0) { rc = FAIL(SWIMM_E_FORMAT, "SWIMM: '%s' holds no FASTA record.", fasta_path); goto done; }
+        (void)munmap((void *)buf, len);
+        buf = NULL;
+        order = stable_length_order(x.len, x.n);
+        if (!order) { rc = FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); goto done; }
+        char name[4096];
+        size_t max_title = 0;
+        /* .desc : title lines (with '>') in sorted order, sequences.c:128-141 */
+        snprintf(name, sizeof name, "%s.desc", out_prefix);
+        fd = fopen(name, "wb");
+        if (!fd) { rc = FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening sequence header file."); goto done; }
+        (void)setvbuf(fd, NULL, _IOFBF, (size_t)4 << 20);
+        for (uint64_t i = 0; i < x.n; ++i) {
+            const uint64_t s = order[i];
+            if (x.title_len[s] > max_title) max_title = x.title_len[s];
+            fwrite(tit + x.title_off[s], 1, x.title_len[s], fd);
+            fputc('\n', fd);
+        }
+        if (ferror(fd)) { rc = FAIL(SWIMM_E_FILE, "SWIMM: write error on '%s.desc'.", out_prefix); goto done; }
+        fclose(fd); fd = NULL;
+        (void)munmap(tit, len + 1);
+        tit = (char *)MAP_FAILED;
+        /* .info : "%ld %ld %d", no newline; max title = longest line incl. '>' + newline + 1 (sequences.c:36,187) */
+        snprintf(name, sizeof name, "%s.info", out_prefix);
+        FILE *fi = fopen(name, "wb");
+        if (!fi) { rc = FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening info file."); goto done; }
+        fprintf(fi, "%ld %ld %d", (long)x.n, (long)w, (int)(max_title + 2));
+        fclose(fi);
+        /* .seq : uint16 lengths, then recoded residues, both in sorted order (sequences.c:201-205) */
+        snprintf(name, sizeof name, "%s.seq", out_prefix);
+        fs = fopen(name, "wb");
+        if (!fs) { rc = FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening sequence file."); goto done; }
+        l16 = (uint16_t *)malloc(x.n * sizeof(uint16_t));
+        const size_t blk = (size_t)64 << 20;
+        out = (char *)malloc(blk);
+        if (!l16 || !out) { rc = FAIL(SWIMM_E_NOMEM, "SWIMM: An error occurred while allocating memory."); goto done; }
+        for (uint64_t i = 0; i < x.n; ++i) l16[i] = (uint16_t)x.len[order[i]];
+        fwrite(l16, sizeof(uint16_t), x.n, fs);
+        size_t fill = 0;                                              /* gather the sorted residues and write them in large blocks */
+        for (uint64_t i = 0; i < x.n; ++i) {
+            const uint64_t s = order[i];
+            size_t L = x.len[s], done_ = 0;
+            while (done_ < L) {
+                const size_t n = L - done_ < blk - fill ? L - done_ : blk - fill;
+                memcpy(out + fill, res + x.seq_off[s] + done_, n);
+                fill += n; done_ += n;
+                if (fill == blk) { fwrite(out, 1, fill, fs); fill = 0; }
+            }
+        }
+        if (fill) fwrite(out, 1, fill, fs);
+        if (ferror(fs)) { rc = FAIL(SWIMM_E_FILE, "SWIMM: write error on '%s.seq'.", out_prefix); goto done; }
+        if (n_sequences) *n_sequences = x.n;
+        if (n_residues) *n_residues = w;
     }
-    int werr = ferror(fs);
-    fclose(fs);
-    if (n_sequences) *n_sequences = f.count;
-    if (n_residues) *n_residues = f.residues;
-    free(order);
-    swimm_fasta_free(&f);
-    if (werr) return FAIL(SWIMM_E_FILE, "SWIMM: write error on '%s.seq'.", out_prefix);
-    return SWIMM_OK;
+done:
+    if (fd) fclose(fd);
+    if (fs) fclose(fs);
+    free(out); free(l16); free(order);
+    free(x.title_off); free(x.seq_off); free(x.title_len); free(x.len);
+    if (buf) (void)munmap((void *)buf, len);
+    if (res != MAP_FAILED) (void)munmap(res, len + 1);
+    if (tit != MAP_FAILED) (void)munmap(tit, len + 1);
+    return rc;
 }
 
 /* ---- preprocessed database ------------------------------------------------------------ */

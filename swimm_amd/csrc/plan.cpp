@@ -207,7 +207,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
         const double cost = k.passes * (k.pass_base * imb + 150e-6);
         if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
             best_cost = cost;
-            out->T = k.T; out->W = k.W; out->passes = k.passes; out->mpad = (uint32_t)(k.passes * k.W * k.T);
+            out->T = k.T; out->W = k.W; out->passes = k.passes; out->mpad = (uint32_t)(k.passes * k.W * k.T); out->est_s = cost;
         }
     }
     // (no admissible shape leaves a lane-systolic wave its registers, e.g. under a max_waves cap: the tail then shares)

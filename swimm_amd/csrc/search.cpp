@@ -182,56 +182,112 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
     return 0;
 }
 
-int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row, hipStream_t st,
-                    LaneScratch &sc)
+// rows per lane of a query's lane-systolic launch: a query of one pass with up to 128 / 256 rows takes 2 / 4 (the serial walk
+// down a lane's rows is the step latency), everything else 8
+int lane_rows_for(const swimm_hip_ctx *c, uint32_t m)
 {
-    if (ll.n == 0) return 0;
-    const int rows_pass = 64 * kLaneRows;
-    const int passes = (m + rows_pass - 1) / rows_pass;
-    const size_t need_bnd = passes > 1 ? (size_t)ll.cols + 64 : 0, need_prog = (size_t)passes * ll.n;
-    if (sc.bnd[0].cap < need_bnd || sc.bnd[1].cap < need_bnd || sc.queue.cap < (size_t)passes || sc.prog.cap < need_prog)
-        return fail("internal: lane scratch too small (%zu/%zu columns, %zu/%zu counters)", sc.bnd[0].cap, need_bnd, sc.prog.cap, need_prog);
-    // never more than one workgroup per CU in total: the whole grid becomes resident (a pass waits for the one
-    // before it), pass-major so that producers are dispatched first; 4 waves per workgroup
-    int per_pass = passes > 1 ? std::max(1, c->num_cu / passes) : c->num_cu * 6;   // a single pass chains nothing: fill the chip
-    per_pass = (int)std::min<uint64_t>(per_pass, (ll.n + 3) / 4);
-    if (passes > c->num_cu) return fail("query of %d rows needs %d chained passes, more than the %d CUs", m, passes, c->num_cu);
-    LaneParams p{};
-    p.items = ll.items.p;
-    p.n_items = ll.n;
-    p.queue = sc.queue.p;
-    p.prog = sc.prog.p;
-    p.prof = c->d_prof.p + qp.prof_off;
-    p.prof_stride = qp.mpad;
-    p.m = (uint32_t)m;
-    p.passes = (uint32_t)passes;
-    p.wg_per_pass = (uint32_t)per_pass;
-    p.bnd[0] = sc.bnd[0].p;
-    p.bnd[1] = sc.bnd[1].p;
-    p.bnd_dummy = (uint32_t)ll.cols;
-    p.out = out_row;
-    p.goe = c->open_gap + c->extend_gap;
-    p.ge = c->extend_gap;
-    p.err = c->d_err.p;
-    p.agent_acquire = c->opt_lane_acquire;
-    HIP_TRY(hipMemsetAsync(sc.queue.p, 0, passes * sizeof(uint32_t), st));
-    if (passes > 1) HIP_TRY(hipMemsetAsync(sc.prog.p, 0, need_prog * sizeof(uint32_t), st));
-    // a one-pass launch of a short query uses fewer rows per lane: the serial walk down a lane's rows is the step latency
-    const int rows_per_lane = (passes == 1 && m <= 128 && c->opt_lane_rows) ? 2 : (passes == 1 && m <= 256 && c->opt_lane_rows) ? 4 : kLaneRows;
-    HIP_TRY(launch_lane(mode, rows_per_lane, passes * per_pass, p, st));
-    c->launches++;
-    c->cells += ll.cell_cols * (uint64_t)rows_pass * passes * (mode == Mode::PK16 ? 2 : 1);
+    if (!c->opt_lane_rows) return kLaneRows;
+    return m <= 128 ? 2 : m <= 256 ? 4 : kLaneRows;
+}
+
+// at most this many boundary columns (8 B each, two buffers) per lane-systolic launch: a batch that needs more is cut
+// into launches that follow each other on the stream
+static const uint64_t kLaneBndColsMax = (uint64_t)1 << 30;
+
+// ONE lane-systolic launch for a batch of queries over the same item list (the long-sequence tail of a range, or the
+// promotion re-runs of one query): every (query, pass) is a set of workgroups with a work cursor of its own, the passes
+// of a query chained item by item through bnd / prog (sw_lane_kernel).  The items are independent chains -- a 35 000-residue
+// sequence is 22 ms per query on one wave, whatever else the chip does -- so the queries of a batch go side by side:
+// c3's 20 queries spend 22 ms + the skew of the chained passes on that chain, not 20 x 22 ms in turn.
+// Never more than one workgroup per CU in total while any query has chained passes: the whole grid becomes resident (a
+// pass waits for the one before it), ascending in pass so that producers are dispatched first; 4 waves per workgroup.
+int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::vector<LaneQuery> &qs, const LaneList &ll, hipStream_t st, LaneScratch &sc)
+{
+    if (ll.n == 0 || qs.empty()) return 0;
+    const int rows_pass = 64 * rows_per_lane;
+    size_t at = 0;
+    while (at < qs.size()) {
+        // the next run of queries that fits the chip (one workgroup per (query, pass) at least) and the boundary budget
+        std::vector<LaneQ> lq;
+        uint32_t pass_total = 0, max_passes = 1;
+        uint64_t bnd_cols = 0;
+        size_t end = at;
+        for (; end < qs.size(); ++end) {
+            const uint32_t passes = (qs[end].m + rows_pass - 1) / rows_pass;
+            if (passes > 255) return fail("query of %u rows needs %u chained lane passes (255 at most)", qs[end].m, passes);
+            if ((int)passes > c->num_cu) return fail("query of %u rows needs %u chained passes, more than the %d CUs", qs[end].m, passes, c->num_cu);
+            if (passes > 1 && rows_per_lane != kLaneRows) return fail("internal: a multi-pass query in a short-lane launch");
+            const uint64_t need = passes > 1 ? ll.cols + 64 : 0;
+            // (launches with chained passes must be resident as a whole: one workgroup per (query, pass) at least, one per CU at most)
+            const uint32_t limit = rows_per_lane == kLaneRows ? (uint32_t)c->num_cu : 4096u;
+            if (end > at && (pass_total + passes > limit || bnd_cols + need > kLaneBndColsMax)) break;
+            LaneQ d{};
+            d.prof_off = qs[end].prof_off; d.out_off = qs[end].out_off; d.bnd0 = bnd_cols; d.prof_stride = qs[end].prof_stride; d.m = qs[end].m;
+            d.passes = passes; d.queue0 = pass_total; d.prog0 = pass_total;
+            lq.push_back(d);
+            pass_total += passes; bnd_cols += need; max_passes = std::max(max_passes, passes);
+        }
+        const size_t need_prog = max_passes > 1 ? (size_t)pass_total * ll.n : 0;
+        if (sc.bnd[0].cap < bnd_cols || sc.bnd[1].cap < bnd_cols || sc.queue.cap < pass_total || sc.prog.cap < need_prog || sc.lq.cap < lq.size())
+            return fail("internal: lane scratch too small (%zu/%llu columns, %zu/%zu counters, %zu/%zu queries)", sc.bnd[0].cap, (unsigned long long)bnd_cols, sc.prog.cap,
+                        need_prog, sc.lq.cap, lq.size());
+        // workgroups per (query, pass): the chip's budget dealt evenly (every (query, pass) walks the same items); a launch
+        // without chained passes may ask for more than the chip holds at once
+        const uint32_t budget = max_passes > 1 ? (uint32_t)c->num_cu : (uint32_t)c->num_cu * 6;
+        uint32_t per = std::max<uint32_t>(1, budget / pass_total);
+        per = (uint32_t)std::min<uint64_t>(per, (ll.n + 3) / 4);
+        std::vector<uint32_t> block_map;
+        block_map.reserve((size_t)per * pass_total);
+        for (uint32_t ps = 0; ps < max_passes; ++ps)
+            for (size_t i = 0; i < lq.size(); ++i)
+                if (ps < lq[i].passes)
+                    for (uint32_t k = 0; k < per; ++k) block_map.push_back((uint32_t)(i << 8) | ps);
+        if (sc.block_map.cap < block_map.size()) return fail("internal: lane scratch too small (%zu/%zu workgroups)", sc.block_map.cap, block_map.size());
+        if (list_copy(c, sc.lq.p, lq.data(), lq.size() * sizeof(LaneQ)) || list_copy(c, sc.block_map.p, block_map.data(), block_map.size() * sizeof(uint32_t)) || list_sync(c)) return 1;
+        LaneParams p{};
+        p.items = ll.items.p;
+        p.n_items = ll.n;
+        p.lq = sc.lq.p;
+        p.block_map = sc.block_map.p;
+        p.queue = sc.queue.p;
+        p.prog = sc.prog.p;
+        p.prof = c->d_prof.p;
+        p.bnd[0] = sc.bnd[0].p;
+        p.bnd[1] = sc.bnd[1].p;
+        p.out = c->d_scores.p;
+        p.goe = c->open_gap + c->extend_gap;
+        p.ge = c->extend_gap;
+        p.err = c->d_err.p;
+        p.agent_acquire = c->opt_lane_acquire;
+        HIP_TRY(hipMemsetAsync(sc.queue.p, 0, pass_total * sizeof(uint32_t), st));
+        if (max_passes > 1) HIP_TRY(hipMemsetAsync(sc.prog.p, 0, need_prog * sizeof(uint32_t), st));
+        HIP_TRY(launch_lane(mode, rows_per_lane, (int)block_map.size(), p, st));
+        c->launches++;
+        c->cells += ll.cell_cols * (uint64_t)rows_pass * pass_total * (mode == Mode::PK16 ? 2 : 1);
+        at = end;
+        // (a further launch of the batch reuses the scratch: the tables above travel on the list stream, so this stream has to
+        // have taken the launch before they are overwritten -- rare: more than num_cu chained passes in one batch)
+        if (at < qs.size()) HIP_TRY(hipStreamSynchronize(st));
+    }
     return 0;
 }
 
-int reserve_lane_scratch(LaneScratch &sc, size_t cols, size_t items, int passes)
+// scratch of a lane-systolic launch of `queries` queries with `pass_total` passes in all over `items` items; bnd_cols:
+// boundary columns of its multi-pass queries together (each: the list's columns + 64)
+int reserve_lane_scratch(swimm_hip_ctx *c, LaneScratch &sc, size_t list_cols, size_t items, size_t pass_total, size_t queries, size_t multi_pass_queries)
 {
-    HIP_TRY(sc.queue.reserve(256));
-    if (passes > 1) {
-        HIP_TRY(sc.bnd[0].reserve(cols + 64));
-        HIP_TRY(sc.bnd[1].reserve(cols + 64));
+    size_t bnd_cols = multi_pass_queries * (list_cols + 64);
+    bnd_cols = std::min<size_t>(bnd_cols, std::max<size_t>(kLaneBndColsMax, list_cols + 64));
+    pass_total = std::min<size_t>(pass_total, 4096 + 255);
+    queries = std::min<size_t>(queries, 4096);
+    HIP_TRY(sc.queue.reserve(std::max<size_t>(256, pass_total)));
+    if (bnd_cols) {
+        HIP_TRY(sc.bnd[0].reserve(bnd_cols));
+        HIP_TRY(sc.bnd[1].reserve(bnd_cols));
     }
-    HIP_TRY(sc.prog.reserve(std::max<size_t>(1, items * (size_t)passes)));
+    HIP_TRY(sc.prog.reserve(std::max<size_t>(1, multi_pass_queries ? items * std::min<size_t>(pass_total, (size_t)c->num_cu + 255) : 1)));
+    HIP_TRY(sc.lq.reserve(std::max<size_t>(1, queries)));
+    HIP_TRY(sc.block_map.reserve((size_t)c->num_cu * 6 + 4096));
     return 0;
 }
 
@@ -249,12 +305,13 @@ struct SearchRun {
     // the database: one range (resident, cached work lists) or the ranges a lazily uploaded database streams in as
     bool streaming = false;
     std::vector<Range> ranges;
-    std::vector<std::pair<size_t, size_t>> range_chunks;     // streaming: positions [first, last) in `up_order` of every range's chunks
-    std::vector<size_t> up_order;                            // streaming: the chunks in the order they travel
+    std::vector<std::pair<size_t, size_t>> range_chunks;     // streaming: positions [first, last) in `up_order` of every range's parts
+    std::vector<UploadPart> up_order;                        // streaming: the chunks (the first one in parts) in the order they travel
     std::vector<std::map<int, DbPlan>> stream_plans;         // streaming: work lists per (range, workgroup count), released when the search has drained
     // the launch plan
     Mode main_mode = Mode::F16;
     bool lane_room = false, many_short = false, alternate = false;
+    bool tall = false;                      // the batch is ONE group-resident launch of tall workgroups beside the tail kernels (plan_queries)
     uint32_t longest_cols = 0;
     std::vector<QueryPlan> qps;
     std::vector<uint8_t> rotated;                            // one-pass queries that run whole (no tail kernel) on three streams in rotation
@@ -324,7 +381,7 @@ int SearchRun::plan_for(size_t ri, int T, int W, bool resident, bool whole_db, D
     if (it == stream_plans[ri].end()) {
         DbPlan &dp = stream_plans[ri][n_wg];
         bool exact = true;
-        for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[up_order[ci]].lens_known;
+        for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[up_order[ci].chunk].lens_known;
         if (make_db_plan(c, main_mode, n_wg, resident, ranges[ri], exact, dp)) return 1;
         *out = &dp;
     } else {
@@ -335,7 +392,7 @@ int SearchRun::plan_for(size_t ri, int T, int W, bool resident, bool whole_db, D
 
 int SearchRun::plan_of(size_t ri, uint32_t q, DbPlan **out)
 {
-    return plan_for(ri, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, rotated[q] != 0 || qps[q].resident, out);
+    return plan_for(ri, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, rotated[q] != 0 || (qps[q].resident && !tall), out);
 }
 
 // Which short queries share workgroups.  Candidates: the one-pass queries of up to 72 rows that run without a tail kernel
@@ -397,6 +454,7 @@ int SearchRun::begin(uint64_t *slots_out)
     if (!c->have_queries) return fail("swimm_hip_search: no queries set");
     if (c->groups.empty()) return fail("swimm_hip_search: no database chunk resident");
     CHECK_DEVICE(c);
+    pool_trim(c);                      // (buffers of a cleared database that the new chunks did not take)
     if (refresh_plans(c)) return 1;
     qn = qe - qb;
     dbg = getenv("SWIMM_HIP_DEBUG") != nullptr;
@@ -438,22 +496,59 @@ int SearchRun::layout_ranges()
         const size_t nc = c->chunks.size();
         const bool descending = nc > 1 && (double)c->chunks[nc - 1].cols / std::max<uint32_t>(1, c->chunks[nc - 1].n_groups) >
                                               (double)c->chunks[0].cols / std::max<uint32_t>(1, c->chunks[0].n_groups);
-        for (size_t i = 0; i < nc; ++i) up_order.push_back(descending ? nc - 1 - i : i);
+        // The chunk that travels first goes in parts -- 16 MiB, 32 MiB, the rest -- so that the first launch has its data
+        // after 0.4 ms instead of the 2 ms a whole 96 MiB chunk takes on the link (the head part is the chunk's end with the
+        // longest sequences when the database travels in descending order).
+        size_t n_part_ev = 0;
+        for (size_t i = 0; i < nc; ++i) {
+            const size_t ci = descending ? nc - 1 - i : i;
+            const ChunkRec &r = c->chunks[ci];
+            const uint64_t bytes = r.kind == 0 ? r.vD : r.code_bytes;
+            bool ascending = true;
+            if (r.kind == 0 && !r.uploaded)
+                for (uint32_t v = 1; v < r.group_count; ++v) ascending = ascending && r.h_disp[v] >= r.h_disp[v - 1];
+            if (i == 0 && !r.uploaded && r.groups_uploaded == 0 && ascending && bytes >= ((uint64_t)56 << 20) && r.n_groups >= 16 && qn <= 4) {
+                const uint64_t heads[2] = {(uint64_t)16 << 20, (uint64_t)32 << 20};
+                uint32_t edge = descending ? r.n_groups : 0;      // the groups still to be dealt: [0, edge) or [edge, n)
+                for (int h = 0; h < 2; ++h) {
+                    uint64_t acc = 0;
+                    uint32_t cut = edge;
+                    if (descending) { while (cut > 8 && acc < heads[h]) { --cut; acc += (uint64_t)r.gcols[cut] * kGroupSeqs; } }
+                    else { while (cut + 8 < r.n_groups && acc < heads[h]) { acc += (uint64_t)r.gcols[cut] * kGroupSeqs; ++cut; } }
+                    while (c->part_ev.size() <= n_part_ev) {
+                        hipEvent_t e;
+                        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                        c->part_ev.push_back(e);
+                    }
+                    UploadPart pt; pt.chunk = ci; pt.g0 = descending ? cut : edge; pt.g1 = descending ? edge : cut; pt.ready = c->part_ev[n_part_ev++];
+                    up_order.push_back(pt);
+                    edge = cut;
+                }
+                UploadPart rest; rest.chunk = ci; rest.g0 = descending ? 0 : edge; rest.g1 = descending ? edge : r.n_groups; rest.ready = r.ready;
+                up_order.push_back(rest);
+            } else {
+                UploadPart pt; pt.chunk = ci; pt.g0 = 0; pt.g1 = r.n_groups; pt.ready = r.ready;
+                up_order.push_back(pt);
+            }
+        }
         double rows = 0;
         for (uint32_t q = 0; q < qn; ++q) rows += qm[q];
-        auto up_s = [&](const ChunkRec &r) { return (double)(r.kind == 0 ? r.vD : r.code_bytes) / 40e9; };
-        auto dp_s = [&](const ChunkRec &r) { return 0.85 * rows * (double)r.cols * kGroupSeqs / 8000e9; };   // (rather too short: the GPU must not wait)
+        auto part_cols = [&](const UploadPart &pt) { uint64_t x = 0; const ChunkRec &r = c->chunks[pt.chunk]; for (uint32_t g = pt.g0; g < pt.g1; ++g) x += r.gcols[g]; return x; };
+        auto up_s = [&](const UploadPart &pt) { return (double)part_cols(pt) * kGroupSeqs / 40e9; };
+        auto dp_s = [&](const UploadPart &pt) { return 0.85 * rows * (double)part_cols(pt) * kGroupSeqs / 8000e9; };   // (rather too short: the GPU must not wait)
         double t_up = 0, t_gpu = 0;
-        for (size_t i = 0; i < nc;) {
-            Range rg; rg.g0 = c->chunks[up_order[i]].group0; rg.g1 = rg.g0 + c->chunks[up_order[i]].n_groups; rg.cols = 0;
+        const size_t np = up_order.size();
+        for (size_t i = 0; i < np;) {
+            Range rg; rg.g0 = c->chunks[up_order[i].chunk].group0 + up_order[i].g0; rg.g1 = c->chunks[up_order[i].chunk].group0 + up_order[i].g1; rg.cols = 0;
             const size_t first = i;
             double work = 0;
             do {
-                const ChunkRec &r = c->chunks[up_order[i]];
-                rg.g0 = std::min(rg.g0, r.group0); rg.g1 = std::max(rg.g1, r.group0 + r.n_groups); rg.cols += r.cols;
-                t_up += up_s(r); work += dp_s(r);
+                const UploadPart &pt = up_order[i];
+                const ChunkRec &r = c->chunks[pt.chunk];
+                rg.g0 = std::min(rg.g0, r.group0 + pt.g0); rg.g1 = std::max(rg.g1, r.group0 + pt.g1); rg.cols += part_cols(pt);
+                t_up += up_s(pt); work += dp_s(pt);
                 ++i;
-            } while (i < nc && t_up + up_s(c->chunks[up_order[i]]) <= t_gpu);
+            } while (i < np && t_up + up_s(up_order[i]) <= t_gpu);
             t_gpu = std::max(t_gpu, t_up) + work;
             ranges.push_back(rg);
             range_chunks.push_back({first, i});
@@ -571,6 +666,43 @@ int SearchRun::plan_queries()
     c->batch_now = batch_formed;
     if (build_stacks()) return 1;
     c->batch_now = false;
+    // A database that is small beside the chip AND has sequences that are long beside a CU's share (Swiss-Prot's shape at a
+    // tenth of its size: 423 groups for 256 CUs, the longest bulk group 4x a CU's mean load): the 4-wave batch above was
+    // rejected because its longest item -- a group through all 43 passes of the longest query at 1.2 us per column-pass, three
+    // workgroups sharing the CU -- would outlast the search, and one launch per pass is bound by the longest group's chain
+    // in EVERY pass while most workgroups idle (c3 at 10 %: 232 ms for 97 ms of work).  Then: ONE group-resident launch
+    // of TALL workgroups -- 12 waves x 24 rows, one workgroup per CU -- whose items are (group, query) pairs: the chain of the
+    // longest item is 20 passes at 0.6 us per column-pass, every CU has an item at all times, and the shape leaves a
+    // lane-systolic wave its 80 registers, so the long-sequence tail runs beside it (all queries' chains in one launch).
+    tall = false;
+    if (!batch_formed && c->opt_tall != 0 && c->opt_dynamic && !streaming && qn >= 2 && main_mode == Mode::F16 && !c->opt_T && !c->opt_W && !c->opt_maxW &&
+        c->opt_resident != 0 && !((uint64_t)qn * S > 0xFFFFFFFFull || prof_elems_bound(qm, qn) > 0xFFFFFFFFull)) {
+        const int T = 24, W = 12;
+        double est_pp = 0, rows_tall = 0;
+        uint32_t n_multi_pp = 0, max_p = 1;
+        for (uint32_t q = 0; q < qn; ++q) {
+            QueryPlan t{};
+            if (choose_plan(c, main_mode, qm[q], lane_room, false, &t)) return 1;
+            est_pp += t.est_s; n_multi_pp += t.passes > 1;
+            const uint32_t ps = (qm[q] + T * W - 1) / (T * W);
+            rows_tall += (double)ps * T * W; max_p = std::max(max_p, ps);
+        }
+        if (n_multi_pp >= 2 && c->opt_alternate) est_pp /= 1.6;          // (two streams: the chains of two queries' passes overlap)
+        plan_imbalance(c, c->num_cu);                                     // (builds the list of bulk groups)
+        const double longest_bulk = c->bulk.cols.empty() ? 0.0 : (double)c->bulk.cols[0];
+        const double est_tall = std::max(rows_tall * (double)c->total_cols * kGroupSeqs / (0.91 * shape_gcups(T, W) * 1e9), longest_bulk * max_p * 0.6e-6) * 1.05;
+        tall = c->opt_tall == 1 || est_tall < 0.85 * est_pp;
+        if (dbg) fprintf(stderr, "swimm_hip: launches per pass estimated at %.1f ms, one launch of 12 x 24-row workgroups at %.1f ms: %s\n", est_pp * 1e3, est_tall * 1e3, tall ? "tall batch" : "per pass");
+        if (tall)
+            for (uint32_t q = 0; q < qn; ++q) {
+                if (rotated[q] || stack_of[q] >= 0) continue;
+                in_batch[q] = 1;
+                qps[q].T = T; qps[q].W = W;
+                qps[q].passes = (int)((qm[q] + T * W - 1) / (T * W));
+                qps[q].mpad = (uint32_t)(qps[q].passes * T * W);
+            }
+    }
+    const bool any_batch = batch_formed || tall;
     std::vector<BulkCols> rbulk;
     if (streaming && !batch_formed && ranges.size() > 1) {
         rqps.assign(ranges.size(), std::vector<QueryPlan>(qn));
@@ -595,7 +727,10 @@ int SearchRun::plan_queries()
                 if (dbg) fprintf(stderr, "swimm_hip:   range %zu: T=%d W=%d passes=%d\n", ri, rqps[ri][q].T, rqps[ri][q].W, rqps[ri][q].passes);
             }
         const uint32_t lane_rows = (uint32_t)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
-        qps[q].mpad = std::max(qps[q].mpad, lane_rows);
+        // (a query's own profile serves the lane-systolic kernel -- tail, promotion re-runs -- and its own pipeline launches; a
+        // member of a stack has neither when no alignment of it can leave the first tier's range)
+        const bool own_profile = stack_of[q] < 0 || (long)qm[q] * c->max_pos >= (main_mode == Mode::F16 ? 2048 : 32767);
+        qps[q].mpad = own_profile ? std::max(qps[q].mpad, lane_rows) : 0;
         qps[q].prof_off = prof_elems;
         prof_elems += (size_t)kCodes * qps[q].mpad;
     }
@@ -609,7 +744,7 @@ int SearchRun::plan_queries()
     uint32_t n_multi = 0;
     for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && !in_batch[q] && qps[q].passes > 1;
     alternate = n_multi >= 2 && c->opt_alternate && !streaming;
-    c->batch_now = batch_formed;
+    c->batch_now = any_batch;
     return 0;
 }
 
@@ -617,6 +752,7 @@ int SearchRun::upload_profiles()
 {
     std::vector<int16_t> prof(prof_elems, 0);
     for (uint32_t q = 0; q < qn; ++q) {
+        if (qps[q].mpad == 0) continue;
         const int8_t *qa = c->qcodes.data() + qdisp[q];
         for (int d = 0; d < kCodes; ++d) {
             int16_t *row = prof.data() + qps[q].prof_off + (size_t)d * qps[q].mpad;
@@ -718,32 +854,29 @@ int SearchRun::size_buffers()
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
-        if (reserve_lane_scratch(c->tail_scratch, tail_cols, tail_items, max_passes)) return 1;
-        // How many queries' tail launches run side by side.  One, normally: the chains are a small part of the search
-        // and a second launch only takes registers from the bulk kernels (c3: -5 %).  But each query costs at least the
-        // longest sequence's chain (0.63 us per column with 8 rows per lane, 22 ms for 35 000 residues), whatever the
-        // size of the database: when those chains add up to more than the bulk work, up to three run at a time.
-        if (tail_items > 0 && !c->batch_now && !many_short) {
-            double chains = 0, rows = 0;
+        // The long-sequence tail of a range: ONE lane-systolic launch per rows-per-lane class (8 / 4 / 2) for all the queries
+        // that have a tail, each class on a stream and a scratch of its own.
+        {
+            size_t passes_of[3] = {0, 0, 0}, queries_of[3] = {0, 0, 0}, multi = 0;
             for (uint32_t q = 0; q < qn; ++q) {
-                const int lane_passes = (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows));
-                const int lr = (lane_passes == 1 && qm[q] <= 128 && c->opt_lane_rows) ? 2 : (lane_passes == 1 && qm[q] <= 256 && c->opt_lane_rows) ? 4 : kLaneRows;
-                chains += (double)longest_cols * 0.63e-6 * lr / kLaneRows * (lane_passes > 1 ? 1.1 : 1.0);
-                rows += qm[q];
+                const int lr = lane_rows_for(c, qm[q]);
+                const int cls = lr == kLaneRows ? 0 : lr == 4 ? 1 : 2;
+                const size_t ps = (qm[q] + 64 * lr - 1) / (64 * lr);
+                passes_of[cls] += ps; queries_of[cls]++; multi += ps > 1;
             }
-            const double bulk = rows * (double)c->total_cols * kGroupSeqs / 8000e9;
-            if (chains > 0.6 * bulk) tail_lanes = (int)std::min(3.0, std::ceil(chains / std::max(0.6 * bulk, 1e-6)));
-            if (dbg) fprintf(stderr, "swimm_hip: tail chains %.1f ms against %.1f ms of bulk work: %d tail launches at a time\n", chains * 1e3, bulk * 1e3, tail_lanes);
-        }
-        for (int i = 0; i + 1 < tail_lanes; ++i) {
-            if (!c->stream_t[i]) {
-                HIP_TRY(hipStreamCreate(&c->stream_t[i]));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_tail_t[i], hipEventDisableTiming));
+            tail_lanes = tail_items > 0 ? 1 + (queries_of[1] > 0) + (queries_of[2] > 0) : 1;
+            if (tail_items > 0 && reserve_lane_scratch(c, c->tail_scratch, tail_cols, tail_items, passes_of[0], queries_of[0], multi)) return 1;
+            for (int i = 0; i < 2; ++i) {
+                if (tail_items == 0 || queries_of[i + 1] == 0) continue;
+                if (!c->stream_t[i]) {
+                    HIP_TRY(hipStreamCreate(&c->stream_t[i]));
+                    HIP_TRY(hipEventCreateWithFlags(&c->ev_tail_t[i], hipEventDisableTiming));
+                }
+                if (reserve_lane_scratch(c, c->tail_scratch_t[i], tail_cols, tail_items, passes_of[i + 1], queries_of[i + 1], 0)) return 1;
             }
-            if (reserve_lane_scratch(c->tail_scratch_t[i], tail_cols, tail_items, max_passes)) return 1;
+            if (dbg && tail_items) fprintf(stderr, "swimm_hip: tail of %zu items: %zu / %zu / %zu queries with 8 / 4 / 2 rows per lane, %zu chained passes in all\n", tail_items, queries_of[0], queries_of[1], queries_of[2], passes_of[0]);
         }
-        if (reserve_lane_scratch(c->tail_scratch_a, 0, tail_items, 1) || reserve_lane_scratch(c->tail_scratch_b, 0, tail_items, 1)) return 1;
-        if (reserve_lane_scratch(c->rerun_scratch, (size_t)1 << 22, 4096, max_passes)) return 1;
+        if (reserve_lane_scratch(c, c->rerun_scratch, (size_t)1 << 22, 4096, max_passes, 1, max_passes > 1 ? 1 : 0)) return 1;
         HIP_TRY(c->d_satlist.reserve((size_t)std::min<uint64_t>(S, 0xFFFFFFFEull) + 1));   // every slot could leave a tier's range
         HIP_TRY(c->d_rerun_items.reserve(4096));
     }
@@ -758,9 +891,9 @@ int SearchRun::issue()
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
-    for (int i = 0; i + 1 < tail_lanes; ++i) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], c->ev_ready, 0));
+    for (int i = 0; i < 2; ++i) if (c->stream_t[i]) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], c->ev_ready, 0));
     HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_ready, 0));
-    uint32_t one_pass_seen = 0, tail_seen = 0;
+    uint32_t one_pass_seen = 0;
     double alt_rows[2] = {0, 0};
     HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
     while (c->ev_query.size() < 2 * (size_t)qn) {
@@ -814,12 +947,40 @@ int SearchRun::issue()
     for (size_t ri = 0; ri < ranges.size(); ++ri) {
         if (streaming) {
             if (wait_uploaded(range_chunks[ri].second)) return 1;
-            ChunkRec &last = c->chunks[up_order[range_chunks[ri].second - 1]];   // the upload stream is in order: its last chunk's event covers the range
+            const UploadPart &last = up_order[range_chunks[ri].second - 1];   // the upload stream is in order: its last part's event covers the range
             if (dbg) fprintf(stderr, "swimm_hip: range %zu (%llu columns): host copies done %.3f ms after the call began\n", ri, (unsigned long long)ranges[ri].cols, (now_s() - t_begin) * 1e3);
             HIP_TRY(hipStreamWaitEvent(c->stream, last.ready, 0));
             HIP_TRY(hipStreamWaitEvent(c->stream_b, last.ready, 0));
             HIP_TRY(hipStreamWaitEvent(c->stream2, last.ready, 0));
-            for (int i = 0; i + 1 < tail_lanes; ++i) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], last.ready, 0));
+            for (int i = 0; i < 2; ++i) if (c->stream_t[i]) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], last.ready, 0));
+        }
+        // The long-sequence tail of this range first (a few long serial chains, one wave each, beside the bulk kernels: 3 bulk
+        // waves of 144 VGPRs + 1 lane wave of 80 fill a SIMD's 512 registers exactly): every query that has one joins ONE
+        // lane-systolic launch per rows-per-lane class, so the chains of all the queries run side by side.
+        {
+            std::vector<LaneQuery> cls[3];
+            std::vector<uint32_t> cls_q[3];
+            const LaneList *ll = nullptr;
+            for (uint32_t k = 0; k < qn; ++k) {
+                const uint32_t q = qn - 1 - k;
+                if (stack_of[q] >= 0 || (qps[q].resident && !tall) || rotated[q]) continue;      // (every group through the pipeline kernel)
+                DbPlan *dp = nullptr;
+                if (plan_of(ri, q, &dp)) return 1;
+                if (dp->tail.n == 0) continue;
+                if (!ll) ll = &dp->tail;                  // (the same items whatever the launch shape: the first list serves all)
+                const int lr = lane_rows_for(c, qm[q]);
+                const int ci = lr == kLaneRows ? 0 : lr == 4 ? 1 : 2;
+                cls[ci].push_back(LaneQuery{qm[q], qps[q].prof_off, qps[q].mpad, (uint64_t)q * S});
+                cls_q[ci].push_back(q);
+            }
+            for (int ci = 0; ci < 3; ++ci) {
+                if (cls[ci].empty()) continue;
+                hipStream_t st = ci == 0 ? c->stream2 : c->stream_t[ci - 1];
+                LaneScratch &sc = ci == 0 ? c->tail_scratch : c->tail_scratch_t[ci - 1];
+                if (run_lane_batch(c, main_mode == Mode::F16 ? Mode::F16 : Mode::PK16, ci == 0 ? kLaneRows : ci == 1 ? 4 : 2, cls[ci], *ll, st, sc)) return 1;
+                if (dbg) fprintf(stderr, "swimm_hip: range %zu: tail of %u items for %zu queries in one launch (%d rows per lane)\n", ri, ll->n, cls[ci].size(), ci == 0 ? kLaneRows : ci == 1 ? 4 : 2);
+                for (uint32_t q : cls_q[ci]) HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], st));
+            }
         }
         // Longest query first: its promotion re-runs (a handful of long serial chains on stream 3) then overlap
         // the bulk kernels of the shorter queries instead of running alone at the end.
@@ -842,20 +1003,15 @@ int SearchRun::issue()
             // 100 residues against 1e8: 3 480 -> 4 750 GCUPS, of 40 residues: 1 570 -> 3 000.  (Three streams, because HIP
             // multiplexes streams onto four hardware queues and the fourth carries the promotion re-runs; with seven
             // streams a tail kernel landed in the bulk stream's queue and held it back: -18 % on c3.)
-            hipStream_t tail_stream = c->stream2, bulk_stream = c->stream;
-            LaneScratch *tail_scratch = &c->tail_scratch;
-            // (with an extreme sequence in the database the short queries keep their tail kernel, but still take turns on
-            // the three streams: three 17 ms chains at a time instead of one)
+            hipStream_t bulk_stream = c->stream;
+            // (with an extreme sequence in the database the short queries keep their tail kernel -- in the launches above -- but
+            // their bulk kernels still take turns on the three streams)
             if (rotated[q] || (many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows)) {
                 switch (one_pass_seen++ % 3) {
-                case 0: tail_stream = bulk_stream = c->stream; tail_scratch = &c->tail_scratch_a; break;
-                case 1: tail_stream = bulk_stream = c->stream_b; tail_scratch = &c->tail_scratch_b; break;
-                default: tail_stream = bulk_stream = c->stream2; break;
+                case 0: bulk_stream = c->stream; break;
+                case 1: bulk_stream = c->stream_b; break;
+                default: bulk_stream = c->stream2; break;
                 }
-            }
-            if (tail_lanes > 1 && dp->tail.n > 0 && tail_stream == c->stream2) {      // chain-bound search: the tail launches take turns on up to three streams
-                const uint32_t ti = tail_seen++ % (uint32_t)tail_lanes;
-                if (ti > 0) { tail_stream = c->stream_t[ti - 1]; tail_scratch = &c->tail_scratch_t[ti - 1]; }
             }
             DevBuf<uint2> *bnd = &c->d_bnd;
             // (the one-pass queries of such a batch take their turn as well: they are the shortest, the batch ends with them,
@@ -868,18 +1024,12 @@ int SearchRun::issue()
                 if (pick) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
             }
             if (streaming && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
-            // (the tail's first tier is the bulk's: binary16 pairs, unless that tier is switched off; the ladder below re-runs
-            // what reaches 2048 in int16 -- rare, the chains are long but the scores are not)
-            if (run_lane_passes(c, main_mode == Mode::F16 ? Mode::F16 : Mode::PK16, qps[q], qm[q], dp->tail, row, tail_stream, *tail_scratch)) return 1;
             if (dbg)
-                fprintf(stderr, "swimm_hip: query %u (%u rows, %d passes of %d x %d): bulk on %s, tail on %s\n", q, qm[q], qp_of(ri, q).passes, qp_of(ri, q).W, qp_of(ri, q).T,
-                        bulk_stream == c->stream ? "stream A" : bulk_stream == c->stream_b ? "stream B" : "the tail stream",
-                        tail_stream == c->stream2 ? "the tail stream" : tail_stream == c->stream ? "stream A" : tail_stream == c->stream_b ? "stream B" : "a further tail stream");
+                fprintf(stderr, "swimm_hip: query %u (%u rows, %d passes of %d x %d): bulk on %s\n", q, qm[q], qp_of(ri, q).passes, qp_of(ri, q).W, qp_of(ri, q).T,
+                        bulk_stream == c->stream ? "stream A" : bulk_stream == c->stream_b ? "stream B" : "the tail stream");
             if (dp->have_main && run_passes(c, main_mode, qp_of(ri, q), dp->main, row, bulk_stream, !streaming && !alternate, *bnd)) return 1;
-            if (ri + 1 == ranges.size()) {
-                HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
-                HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], tail_stream));
-            }
+            HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
+            if (dp->tail.n == 0 || rotated[q]) HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], bulk_stream));      // (no tail launch recorded it above)
         }
         // The stacks of short queries that run in rotation (no group-resident batch): one per-pass launch per stack, on
         // the three streams in turn like the single short queries above.
@@ -912,7 +1062,7 @@ int SearchRun::issue()
                 const int T = kv.first.first, W = kv.first.second;
                 const uint32_t nqb = (uint32_t)kv.second.size();
                 DbPlan *dp = nullptr;
-                if (plan_for(ri, T, W, true, true, &dp)) return 1;
+                if (plan_for(ri, T, W, true, !tall, &dp)) return 1;
                 uint64_t pass_sum = 0;
                 uint32_t max_p = 1;
                 for (const Unit &u : kv.second) {
@@ -943,7 +1093,8 @@ int SearchRun::issue()
                     if (u.stack >= 0) {
                         for (uint32_t q : stacks[u.stack].q) { HIP_TRY(hipEventRecord(c->ev_query[2 * q], st)); HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], st)); }
                     } else {
-                        HIP_TRY(hipEventRecord(c->ev_query[2 * u.q], st)); HIP_TRY(hipEventRecord(c->ev_query[2 * u.q + 1], st));
+                        HIP_TRY(hipEventRecord(c->ev_query[2 * u.q], st));
+                        if (!tall || dp->tail.n == 0) HIP_TRY(hipEventRecord(c->ev_query[2 * u.q + 1], st));      // (a tall batch's members have their tail launch's event)
                     }
                 }
                 ++bi;
@@ -966,7 +1117,8 @@ int SearchRun::issue()
         // (a chain-bound search rotates its tail launches over further streams, range after range: a query's tail kernel
         // of an EARLY range may sit on one of them while ev_query[2q + 1] only marks the last range's -- the promotion
         // ladder must not scan a score row a lane kernel is still writing)
-        for (int i = 0; i + 1 < tail_lanes; ++i) {
+        for (int i = 0; i < 2; ++i) {
+            if (!c->stream_t[i]) continue;
             HIP_TRY(hipEventRecord(c->ev_tail_t[i], c->stream_t[i]));
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail_t[i], 0));
         }
@@ -1014,14 +1166,14 @@ int SearchRun::promotion_ladder()
                 // growing a buffer frees the old one, which waits for the whole device: rare (first big batch)
                 HIP_TRY(hipDeviceSynchronize());
                 HIP_TRY(c->d_rerun_items.reserve(items.size() * 2));
-                if (reserve_lane_scratch(c->rerun_scratch, cols * 2, items.size() * 2, rpasses)) return 1;
+                if (reserve_lane_scratch(c, c->rerun_scratch, cols * 2, items.size() * 2, rpasses, 1, rpasses > 1 ? 1 : 0)) return 1;
             }
             HIP_TRY(hipMemcpyAsync(c->d_rerun_items.p, items.data(), items.size() * sizeof(LaneItem), hipMemcpyHostToDevice, c->stream3));
             HIP_TRY(hipStreamSynchronize(c->stream3));       // `items` is a host temporary
             LaneList ll;
             ll.items.p = c->d_rerun_items.p; ll.items.cap = c->d_rerun_items.cap;
             ll.n = (uint32_t)items.size(); ll.cols = cols; ll.cell_cols = cols;
-            const int rc = run_lane_passes(c, mode, qps[q], qm[q], ll, c->d_scores.p + (size_t)q * S, c->stream3, c->rerun_scratch);
+            const int rc = run_lane_batch(c, mode, kLaneRows, std::vector<LaneQuery>{LaneQuery{qm[q], qps[q].prof_off, qps[q].mpad, (uint64_t)q * S}}, ll, c->stream3, c->rerun_scratch);
             ll.items.p = nullptr; ll.items.cap = 0;           // borrowed
             return rc;
         };
@@ -1073,7 +1225,8 @@ int SearchRun::drain()
 {
     HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
-    for (int i = 0; i + 1 < tail_lanes; ++i) {
+    for (int i = 0; i < 2; ++i) {
+        if (!c->stream_t[i]) continue;
         HIP_TRY(hipEventRecord(c->ev_tail_t[i], c->stream_t[i]));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail_t[i], 0));
     }

@@ -87,18 +87,28 @@ struct LaneItem {
     uint32_t bnd_off;      // first column of this item in the pass-boundary buffer
     uint32_t pad_;
 };
-struct LaneParams {
-    const LaneItem *items;
-    uint32_t n_items;
-    uint32_t *queue;            // [passes] work cursors, zeroed before the launch
-    uint32_t *prog;             // [passes][n_items] boundary columns published so far (global column + 1), zeroed
-    const int16_t *prof;
+// one query of a lane-systolic launch (a launch serves a batch of queries: their tail items are independent chains,
+// and 20 queries x the 22 ms chain of a 35 000-residue sequence run side by side instead of one after the other)
+struct LaneQ {
+    uint64_t prof_off;          // first element of the query's profile in LaneParams::prof
+    uint64_t out_off;           // first element of the query's score row in LaneParams::out
+    uint64_t bnd0;              // first column of the query's boundary rows in bnd[0] / bnd[1] (multi-pass queries)
     uint32_t prof_stride;
     uint32_t m;                 // query rows
-    uint32_t passes;            // ceil(m / (64 * kLaneRows)); all passes run in ONE launch, chained per item
-    uint32_t wg_per_pass;       // grid = passes * wg_per_pass workgroups, pass-major
+    uint32_t passes;            // ceil(m / (64 * rows per lane)); all passes run in ONE launch, chained per item
+    uint32_t queue0;            // queue[queue0 + pass]: work cursor of (query, pass), zeroed before the launch
+    uint32_t prog0;             // prog[(prog0 + pass) * n_items + item]: boundary columns published so far (global column + 1), zeroed
+    uint32_t pad_;
+};
+struct LaneParams {
+    const LaneItem *items;      // the same list for every query of the launch
+    uint32_t n_items;
+    const LaneQ *lq;
+    const uint32_t *block_map;  // [grid]: query << 8 | pass of every workgroup, ascending in pass (a producer is dispatched before its consumers)
+    uint32_t *queue;
+    uint32_t *prog;
+    const int16_t *prof;
     unsigned long long *bnd[2]; // boundary rows (H | F << 32 per column): pass p writes bnd[p & 1], reads bnd[(p - 1) & 1]
-    uint32_t bnd_dummy;         // first index of a 64-entry dump area behind the real columns
     int32_t *out;
     int goe, ge;
     uint32_t *err;              // watchdog word
@@ -128,9 +138,10 @@ hipError_t launch_tile_sequences(const uint8_t *codes, const uint32_t *seq_off /
 
 // appends the slots whose score is >= thr (tier left its exact range) to list (up to cap) and zeroes them
 hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, int thr, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s);
-// per-block top-64 candidates of one query's score row: out_keys[block*64 + i] = ((score<<32 | global index) + 1),
-// 0 = empty; group_base[g] = global sorted index of the group's first sequence, group_valid[g] = real sequences in it
+// per-block top-64 candidates of every query's score row (rows n_slots apart): out_keys[(query * n_blocks + block) * 64 + i] =
+// ((score<<32 | global index) + 1), 0 = empty; group_base[g] = global sorted index of the group's first sequence,
+// group_valid[g] = real sequences in it
 hipError_t launch_topk64(const int32_t *scores, uint64_t n_slots, const int64_t *group_base, const uint32_t *group_valid,
-                         unsigned long long *out_keys, int n_blocks, hipStream_t s);
+                         unsigned long long *out_keys, int n_blocks, uint32_t n_queries, hipStream_t s);
 
 }  // namespace swimm

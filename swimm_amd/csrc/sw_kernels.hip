@@ -807,20 +807,23 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int PS = prof_row_bytes(RP);
-    const uint32_t pass = blockIdx.x / p.wg_per_pass;
+    const uint32_t bm = p.block_map[blockIdx.x];
+    const uint32_t pass = bm & 0xffu;
+    const LaneQ lq = p.lq[bm >> 8];
     const uint32_t r0 = pass * RP;
-    const uint32_t rows = p.m - r0 < (uint32_t)RP ? p.m - r0 : (uint32_t)RP;
-    const bool first_pass = pass == 0, last_pass = pass + 1 == p.passes;
-    uint32_t *const queue = p.queue + pass;
-    const uint32_t *const prog_in = p.prog + (first_pass ? 0 : (size_t)(pass - 1) * p.n_items);   // only read when pass > 0
-    uint32_t *const prog_out = p.prog + (size_t)pass * p.n_items;
-    const unsigned long long *const bnd_in = p.bnd[(pass + 1) & 1];
-    unsigned long long *const bnd_out = p.bnd[pass & 1];
+    const uint32_t rows = lq.m - r0 < (uint32_t)RP ? lq.m - r0 : (uint32_t)RP;
+    const bool first_pass = pass == 0, last_pass = pass + 1 == lq.passes;
+    uint32_t *const queue = p.queue + lq.queue0 + pass;
+    const uint32_t *const prog_in = p.prog + (size_t)(lq.prog0 + (first_pass ? 0 : pass - 1)) * p.n_items;   // only read when pass > 0
+    uint32_t *const prog_out = p.prog + (size_t)(lq.prog0 + pass) * p.n_items;
+    const unsigned long long *const bnd_in = p.bnd[(pass + 1) & 1] + lq.bnd0;
+    unsigned long long *const bnd_out = p.bnd[pass & 1] + lq.bnd0;
+    int32_t *const out = p.out + lq.out_off;
     {
         const int dw_per_code = RP >> 1;
         for (int idx = threadIdx.x; idx < kCodes * dw_per_code; idx += blockDim.x) {
             const int d = idx / dw_per_code, x = idx - d * dw_per_code;
-            const uint32_t *src = (const uint32_t *)(p.prof + (size_t)d * p.prof_stride + r0);
+            const uint32_t *src = (const uint32_t *)(p.prof + lq.prof_off + (size_t)d * lq.prof_stride + r0);
             uint32_t v = src[x];
             if (M == 2) {                           // int16 scores -> binary16
                 const v2s sv = as_v2s(v);
@@ -993,14 +996,14 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
                 const LaneItem *iv = p.items + Sin;
                 if (M == 2) {
                     const v2h b2 = __builtin_bit_cast(v2h, oT);
-                    atomicMax(p.out + iv->slot_a, (int)(float)b2.x);
-                    atomicMax(p.out + iv->slot_b, (int)(float)b2.y);
+                    atomicMax(out + iv->slot_a, (int)(float)b2.x);
+                    atomicMax(out + iv->slot_b, (int)(float)b2.y);
                 } else if (PK) {
                     const v2s b2 = __builtin_bit_cast(v2s, oT);
-                    atomicMax(p.out + iv->slot_a, (int)b2.x);
-                    atomicMax(p.out + iv->slot_b, (int)b2.y);
+                    atomicMax(out + iv->slot_a, (int)b2.x);
+                    atomicMax(out + iv->slot_b, (int)b2.y);
                 } else {
-                    atomicMax(p.out + iv->slot_a, (int)oT);
+                    atomicMax(out + iv->slot_a, (int)oT);
                 }
             }
             // advance both streams
@@ -1032,7 +1035,7 @@ hipError_t launch_lane(Mode mode, int rows_per_lane, int n_wg, const LaneParams 
 {
     if (n_wg < 1) return hipErrorInvalidValue;
     if (rows_per_lane == 8) return launch_lane_tr<8>(mode, n_wg, p, s);
-    if (p.passes != 1) return hipErrorInvalidValue;          // the short-lane variants are for one-pass queries
+    // (the short-lane variants are for one-pass queries: the host only puts queries of <= 256 / <= 128 rows into such a launch)
     if (rows_per_lane == 4) return launch_lane_tr<4>(mode, n_wg, p, s);
     if (rows_per_lane == 2) return launch_lane_tr<2>(mode, n_wg, p, s);
     return hipErrorInvalidValue;
@@ -1221,11 +1224,14 @@ __device__ __forceinline__ unsigned long long wave_merge_desc(unsigned long long
     return v;
 }
 
-__global__ void __launch_bounds__(256) topk64_kernel(const int32_t *__restrict__ scores, uint64_t n_slots,
+__global__ void __launch_bounds__(256) topk64_kernel(const int32_t *__restrict__ scores_all, uint64_t n_slots,
                                                      const int64_t *__restrict__ group_base,
                                                      const uint32_t *__restrict__ group_valid,
-                                                     unsigned long long *__restrict__ out_keys)
+                                                     unsigned long long *__restrict__ out_keys_all)
 {
+    // blockIdx.y = query: its score row (n_slots apart) and its gridDim.x * 64 candidate keys
+    const int32_t *__restrict__ scores = scores_all + (size_t)blockIdx.y * n_slots;
+    unsigned long long *__restrict__ out_keys = out_keys_all + (size_t)blockIdx.y * gridDim.x * 64;
     __shared__ unsigned long long sh[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long top = 0;                          // key 0 = empty (real keys have index >= 0, score >= 0: key 0 only for (0, 0), handled by +1 below)
@@ -1252,9 +1258,13 @@ __global__ void __launch_bounds__(256) topk64_kernel(const int32_t *__restrict__
 }
 
 hipError_t launch_topk64(const int32_t *scores, uint64_t n_slots, const int64_t *group_base, const uint32_t *group_valid,
-                         unsigned long long *out_keys, int n_blocks, hipStream_t s)
+                         unsigned long long *out_keys, int n_blocks, uint32_t n_queries, hipStream_t s)
 {
-    hipLaunchKernelGGL(topk64_kernel, dim3(n_blocks), dim3(256), 0, s, scores, n_slots, group_base, group_valid, out_keys);
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += 65535) {          // (gridDim.y limit)
+        const uint32_t nq = n_queries - q0 < 65535 ? n_queries - q0 : 65535;
+        hipLaunchKernelGGL(topk64_kernel, dim3(n_blocks, nq), dim3(256), 0, s, scores + (size_t)q0 * n_slots, n_slots, group_base, group_valid,
+                           out_keys + (size_t)q0 * n_blocks * 64);
+    }
     return hipGetLastError();
 }
 

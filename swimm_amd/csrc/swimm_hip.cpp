@@ -95,9 +95,11 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     (void)ctx_enter(c);
     delete c->up; c->up = nullptr;
     swimm_hip_clear_db(c);
+    pool_trim(c);
+    for (hipEvent_t e : c->part_ev) (void)hipEventDestroy(e);
     c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_qdesc.release(); c->d_wave_out.release();
     if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = c->pin_used = 0; }
-    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_a.release(); c->tail_scratch_b.release(); c->tail_scratch_t[0].release(); c->tail_scratch_t[1].release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
+    c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_t[0].release(); c->tail_scratch_t[1].release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
@@ -271,7 +273,12 @@ int swimm_hip_clear_db(swimm_hip_ctx *c)
     if (!c) return fail("swimm_hip_clear_db: NULL ctx");
     if (ctx_enter(c)) return 1;
     (void)hipDeviceSynchronize();                 // nothing in flight may still read the chunks
-    for (auto &ch : c->chunks) { (void)hipFree(ch.d_tiled); (void)hipFree(ch.d_len); if (ch.ready) (void)hipEventDestroy(ch.ready); }
+    pool_trim(c);                                  // (whatever an earlier database left and nobody took)
+    for (auto &ch : c->chunks) {
+        if (ch.d_tiled) c->pool.push_back({(void *)ch.d_tiled, ch.tiled_cap});
+        if (ch.d_len) c->pool.push_back({(void *)ch.d_len, ch.len_cap});
+        if (ch.ready) (void)hipEventDestroy(ch.ready);
+    }
     c->chunks.clear(); c->groups.clear(); c->group_col_off.clear(); c->seq_len.clear();
     c->total_cols = 0;
     release_plans(c);
@@ -350,15 +357,15 @@ int swimm_hip_search_topr(swimm_hip_ctx *c, uint32_t r, uint64_t n_valid, int32_
                     gbase[ch.group0 + i] = (int64_t)first;
                     gvalid[ch.group0 + i] = (uint32_t)cnt;
                 }
-            const int n_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(256, S / 1024));
+            // (blocks per query: enough to fill the chip over the whole batch; every block's 64 candidates come back to the host,
+            // so a batch of 1 000 queries takes 8 per query, not 256)
+            const int n_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(8, 4096 / qn), std::min<uint64_t>(256, S / 1024)));
             HIP_TRY(c->d_gbase.reserve(gbase.size()));
             HIP_TRY(c->d_gvalid.reserve(gvalid.size()));
             HIP_TRY(c->d_keys.reserve((size_t)qn * n_blocks * 64));
             HIP_TRY(hipMemcpyAsync(c->d_gbase.p, gbase.data(), gbase.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(c->d_gvalid.p, gvalid.data(), gvalid.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            for (uint32_t q = 0; q < qn; ++q)
-                HIP_TRY(launch_topk64(c->d_scores.p + (size_t)q * S, S, c->d_gbase.p, c->d_gvalid.p,
-                                      c->d_keys.p + (size_t)q * n_blocks * 64, n_blocks, c->stream));
+            HIP_TRY(launch_topk64(c->d_scores.p, S, c->d_gbase.p, c->d_gvalid.p, c->d_keys.p, n_blocks, qn, c->stream));
             std::vector<unsigned long long> keys((size_t)qn * n_blocks * 64);
             HIP_TRY(hipMemcpyAsync(keys.data(), c->d_keys.p, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -476,6 +483,9 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "rotate")) {
         c->opt_rotate = value != 0;
+    } else if (!strcmp(key, "tall")) {
+        if (value < -1 || value > 1) return fail("tall must be -1 (auto), 0 or 1");
+        c->opt_tall = value;
     } else if (!strcmp(key, "stack")) {
         c->opt_stack = value != 0;
     } else if (!strcmp(key, "lane_rows")) {

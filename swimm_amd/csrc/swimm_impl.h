@@ -108,8 +108,13 @@ struct DbPlan {          // per (mode, n_wg): main partition + the groups handed
 struct LaneScratch {
     DevBuf<unsigned long long> bnd[2];
     DevBuf<uint32_t> queue, prog;
-    void release() { bnd[0].release(); bnd[1].release(); queue.release(); prog.release(); }
+    DevBuf<LaneQ> lq;                   // the launch's queries
+    DevBuf<uint32_t> block_map;         // (query, pass) of every workgroup
+    void release() { bnd[0].release(); bnd[1].release(); queue.release(); prog.release(); lq.release(); block_map.release(); }
 };
+
+// one query of a lane-systolic launch, as the host hands it over
+struct LaneQuery { uint32_t m; uint64_t prof_off; uint32_t prof_stride; uint64_t out_off; };
 
 struct Uploader;      // the thread that copies a lazily uploaded database (below, with upload_chunk)
 
@@ -132,11 +137,18 @@ struct ChunkRec {
     std::vector<uint64_t> goff; // byte offset of every device group in d_tiled
     std::vector<uint32_t> gcols;
     bool uploaded = false, lens_known = false;
+    uint32_t groups_uploaded = 0;   // device groups on the device so far (a chunk may travel in parts)
+    size_t tiled_cap = 0, len_cap = 0;   // sizes of the two device buffers (they go back to the context's pool)
     hipEvent_t ready = nullptr; // recorded on the upload stream behind the chunk's (re-)tile kernel
 };
 
+// what travels in one go: the device groups [g0, g1) of a chunk (the whole chunk, or -- for the chunk a streaming search
+// starts with -- a small head part, so that the first launch has its data a few hundred microseconds after the call)
+struct UploadPart { size_t chunk = 0; uint32_t g0 = 0, g1 = 0; hipEvent_t ready = nullptr; };
+
 struct QueryPlan {
     int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true, resident = false;
+    double est_s = 0;                   // choose_plan: the predicted time of the query's launches (makespan of the work lists included)
     bool stack = false;                 // the "query" is a stack of short queries sharing one workgroup (QDesc in sw_kernels.h) ...
     uint32_t seam_mask = 0, wave_tab = 0;   // ... with these seams and this first entry in d_wave_out
 };
@@ -183,6 +195,7 @@ struct swimm_hip_ctx {
     bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
     DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
     DevBuf<uint32_t> d_wave_out;        // stacks of short queries: per (stack, wave) the first element of the wave's member's score row
+    int opt_tall = -1;                  // group-resident batches of TALL workgroups (12 x 24 rows, one per CU) beside the tail kernels for a database whose per-pass launches would be chain-bound: -1 = by estimate, 0 never, 1 whenever the 4-wave batch is not formed
     int opt_stack = 1;                  // 1: short one-pass queries of a batch share workgroups (several queries stacked along the strips)
     int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
     std::vector<hipEvent_t> launch_ev;  // pairs (before, after), grown on demand
@@ -228,11 +241,11 @@ struct swimm_hip_ctx {
     DevBuf<uint32_t> d_gvalid;
     DevBuf<unsigned long long> d_keys;
     DevBuf<uint32_t> d_err;             // pipeline watchdog word
+    std::vector<hipEvent_t> part_ev;    // events of the head parts of a streaming search's first chunk (grown on demand)
+    std::vector<std::pair<void *, size_t>> pool;   // device buffers of a cleared database, kept for the chunks registered next (freed by the next search)
     DevBuf<unsigned long long> d_stamps;   // diagnostic build only
-    LaneScratch tail_scratch;           // lane kernel on stream 2 (long-sequence tail)
-    LaneScratch tail_scratch_a, tail_scratch_b;   // one-pass queries that run whole on the main stream / on stream_b
-    // a search whose time is set by the long-sequence chains (a small database with one extreme sequence, many queries)
-    // runs up to three queries' tail launches side by side: two more streams (created on first use), scratch and events
+    LaneScratch tail_scratch;           // lane kernel on stream 2 (long-sequence tail: the launch of the queries with 8 rows per lane)
+    // the tail launches of the short queries (4 and 2 rows per lane) run beside it: two more streams (created on first use), scratch and events
     hipStream_t stream_t[2] = {nullptr, nullptr};
     hipEvent_t ev_tail_t[2] = {nullptr, nullptr};
     LaneScratch tail_scratch_t[2];
@@ -269,6 +282,7 @@ inline int ctx_enter(swimm_hip_ctx *c)
     } while (0)
 
 int upload_chunk(swimm_hip_ctx *c, ChunkRec &r);
+int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEvent_t ready);
 
 // The uploader of a database that streams in (option "lazy_upload"): a thread of its own, one per context, started when
 // the first chunk is recorded and parked between searches.  The copies come from pageable memory, so each one blocks its
@@ -281,7 +295,7 @@ struct Uploader {
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<size_t> order;      // the job: chunk indices in the order they travel
+    std::vector<UploadPart> order;  // the job: the parts in the order they travel
     bool have_job = false, busy = false, quit = false, stop = false;
     size_t issued = 0;              // the first `issued` chunks of `order` have their `ready` event recorded
     bool failed = false;
@@ -302,14 +316,14 @@ struct Uploader {
             cv.wait(lk, [&]() { return have_job || quit; });
             if (quit) return;
             have_job = false;
-            const std::vector<size_t> job = order;
+            const std::vector<UploadPart> job = order;
             lk.unlock();
             bool ok = dev_ok;
             std::string e = ok ? "" : "uploader: hipSetDevice failed";
             for (size_t i = 0; i < job.size(); ++i) {
                 bool skip;
                 { std::lock_guard<std::mutex> g(mu); skip = stop; }
-                if (ok && !skip && upload_chunk(c, c->chunks[job[i]])) { ok = false; e = g_err; }
+                if (ok && !skip && upload_part(c, c->chunks[job[i].chunk], job[i].g0, job[i].g1, job[i].ready)) { ok = false; e = g_err; }
                 std::lock_guard<std::mutex> g(mu);
                 issued = i + 1; failed = !ok; err = e;
                 cv.notify_all();
@@ -319,7 +333,7 @@ struct Uploader {
             cv.notify_all();
         }
     }
-    void post(const std::vector<size_t> &job)
+    void post(const std::vector<UploadPart> &job)
     {
         { std::lock_guard<std::mutex> lk(mu); order = job; issued = 0; failed = false; err.clear(); stop = false; have_job = true; busy = true; }
         cv.notify_all();
@@ -373,6 +387,8 @@ int refresh_plans(swimm_hip_ctx *c);
 int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> &lens_or_empty);
 int ensure_uploader(swimm_hip_ctx *c);
 int sync_lengths(swimm_hip_ctx *c);
+int pool_alloc(swimm_hip_ctx *c, size_t bytes, void **out, size_t *cap);
+void pool_trim(swimm_hip_ctx *c);
 
 // ---- search.cpp: the launches of one search
 int timed_launch(swimm_hip_ctx *c, Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t st);
@@ -380,9 +396,9 @@ uint64_t resident_bnd_elems(const Plan &pl);
 int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl, const QDesc *qd, uint32_t nq, uint64_t pass_sum, uint32_t max_passes,
                        hipStream_t st, DevBuf<uint2> &bnd);
 int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st, bool allow_split, DevBuf<uint2> &bnd);
-int run_lane_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, int m, const LaneList &ll, int32_t *out_row, hipStream_t st,
-                    LaneScratch &sc);
-int reserve_lane_scratch(LaneScratch &sc, size_t cols, size_t items, int passes);
+int lane_rows_for(const swimm_hip_ctx *c, uint32_t m);
+int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::vector<LaneQuery> &qs, const LaneList &ll, hipStream_t st, LaneScratch &sc);
+int reserve_lane_scratch(swimm_hip_ctx *c, LaneScratch &sc, size_t list_cols, size_t items, size_t pass_total, size_t queries, size_t multi_pass_queries);
 int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_out);
 
 }  // namespace swimm_impl

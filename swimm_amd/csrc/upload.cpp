@@ -12,6 +12,30 @@ int refresh_plans(swimm_hip_ctx *c)
     return 0;
 }
 
+// Device buffers of the chunks: a caller that replaces its database (clear_db, then add_chunk / add_sequences) gets the old
+// database's buffers back instead of paying a hipFree and a hipMalloc per chunk (round 1 measured seven such pairs at most
+// of 48 ms).  The pool only bridges that gap: whatever the newly registered chunks did not take is freed by the next search.
+int pool_alloc(swimm_hip_ctx *c, size_t bytes, void **out, size_t *cap)
+{
+    size_t best = c->pool.size();
+    for (size_t i = 0; i < c->pool.size(); ++i)
+        if (c->pool[i].second >= bytes && c->pool[i].second <= bytes + bytes / 4 + (1u << 20) && (best == c->pool.size() || c->pool[i].second < c->pool[best].second)) best = i;
+    if (best < c->pool.size()) {
+        *out = c->pool[best].first; *cap = c->pool[best].second;
+        c->pool.erase(c->pool.begin() + best);
+        return 0;
+    }
+    HIP_TRY(hipMalloc(out, bytes));
+    *cap = bytes;
+    return 0;
+}
+
+void pool_trim(swimm_hip_ctx *c)
+{
+    for (auto &b : c->pool) (void)hipFree(b.first);
+    c->pool.clear();
+}
+
 // Registers a chunk's device groups (geometry only: nothing is copied here).
 int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> &lens_or_empty)
 {
@@ -19,10 +43,10 @@ int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> 
     const uint32_t dev_groups = rec.n_groups;
     uint64_t bytes = 0;
     for (uint32_t g = 0; g < dev_groups; ++g) { rec.goff[g] = bytes; bytes += (uint64_t)rec.gcols[g] * kGroupSeqs; }
-    HIP_TRY(hipMalloc((void **)&rec.d_tiled, std::max<uint64_t>(bytes, 16)));
-    if (rec.kind == 0) {
-        hipError_t e = hipMalloc((void **)&rec.d_len, (size_t)dev_groups * kGroupSeqs * sizeof(uint32_t));
-        if (e != hipSuccess) { (void)hipFree(rec.d_tiled); rec.d_tiled = nullptr; return fail("hipMalloc(sequence lengths): %s", hipGetErrorString(e)); }
+    if (pool_alloc(c, std::max<uint64_t>(bytes, 16), (void **)&rec.d_tiled, &rec.tiled_cap)) return 1;
+    if (rec.kind == 0 && pool_alloc(c, (size_t)dev_groups * kGroupSeqs * sizeof(uint32_t), (void **)&rec.d_len, &rec.len_cap)) {
+        (void)hipFree(rec.d_tiled); rec.d_tiled = nullptr;
+        return 1;
     }
     if (hipEventCreateWithFlags(&rec.ready, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(rec.d_tiled); (void)hipFree(rec.d_len);
@@ -50,52 +74,68 @@ int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> 
     return 0;
 }
 
-// X2 (MICsearch.c:85-88): one chunk's bytes to the device and into device groups, all on the upload stream.  The
-// copies come from pageable memory, so every hipMemcpyAsync returns only when its source has been consumed; what
-// stays asynchronous is the (re-)tile kernel, whose end `ready` marks.  Scratch is reused chunk after chunk (the
-// stream is in order: the next chunk's copy cannot overtake this chunk's kernel).
-int upload_chunk(swimm_hip_ctx *c, ChunkRec &r)
+// X2 (MICsearch.c:85-88): the device groups [g0, g1) of a chunk -- normally all of it -- to the device and into the tiled
+// layout, all on the upload stream.  The copies come from pageable memory, so every hipMemcpyAsync returns only when its
+// source has been consumed; what stays asynchronous is the (re-)tile kernel, whose end `ready` marks.  Scratch is reused
+// part after part (the stream is in order: the next copy cannot overtake this part's kernel).  The kernels index groups,
+// lane groups and sequences from 0: a part hands them its own slices, and the byte / residue offsets inside those slices
+// stay absolute, so the scratch pointer is moved back by the part's first byte.
+int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEvent_t ready)
 {
-    if (r.uploaded) return 0;
+    if (r.uploaded || g0 >= g1) return 0;
     CHECK_DEVICE(c);
     hipStream_t s = c->stream_up;
-    const uint32_t dev_groups = r.n_groups;
+    const uint32_t dev_groups = g1 - g0;
     uint32_t max_cols = 0;
-    for (uint32_t x : r.gcols) max_cols = std::max(max_cols, x);
+    for (uint32_t g = g0; g < g1; ++g) max_cols = std::max(max_cols, r.gcols[g]);
     const double t_up0 = now_s();
+    uint64_t bytes = 0;
     HIP_TRY(c->up_gcols.reserve(dev_groups));
     HIP_TRY(c->up_goff.reserve(dev_groups));
-    HIP_TRY(hipMemcpyAsync(c->up_gcols.p, r.gcols.data(), dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->up_goff.p, r.goff.data(), dev_groups * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->up_gcols.p, r.gcols.data() + g0, dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->up_goff.p, r.goff.data() + g0, dev_groups * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     if (r.kind == 0) {
-        HIP_TRY(c->up_b.reserve(std::max<uint64_t>(r.vD, 16)));
-        HIP_TRY(c->up_n.reserve(r.group_count));
-        HIP_TRY(c->up_disp.reserve(r.group_count));
-        HIP_TRY(hipMemsetAsync(r.d_len, 0, (size_t)dev_groups * kGroupSeqs * sizeof(uint32_t), s));
-        HIP_TRY(hipMemcpyAsync(c->up_n.p, r.h_n, r.group_count * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->up_disp.p, r.h_disp, r.group_count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_b, r.vD, hipMemcpyHostToDevice, s));
+        const uint32_t per = kGroupSeqs / r.vl;
+        const uint32_t v0 = g0 * per, v1 = std::min(r.group_count, g1 * per);
+        uint64_t b0 = r.h_disp[v0], b1 = b0;
+        for (uint32_t v = v0; v < v1; ++v) { b0 = std::min<uint64_t>(b0, r.h_disp[v]); b1 = std::max<uint64_t>(b1, (uint64_t)r.h_disp[v] + (uint64_t)r.h_n[v] * r.vl); }
+        bytes = b1 - b0;
+        HIP_TRY(c->up_b.reserve(std::max<uint64_t>(bytes, 16)));
+        HIP_TRY(c->up_n.reserve(v1 - v0));
+        HIP_TRY(c->up_disp.reserve(v1 - v0));
+        HIP_TRY(hipMemsetAsync(r.d_len + (size_t)g0 * kGroupSeqs, 0, (size_t)dev_groups * kGroupSeqs * sizeof(uint32_t), s));
+        HIP_TRY(hipMemcpyAsync(c->up_n.p, r.h_n + v0, (v1 - v0) * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->up_disp.p, r.h_disp + v0, (v1 - v0) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_b + b0, bytes, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(c->ev_copied, s));
-        HIP_TRY(launch_retile(c->up_b.p, c->up_n.p, c->up_disp.p, r.group_count, r.vl, c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled, r.d_len, s));
+        HIP_TRY(launch_retile(c->up_b.p - b0, c->up_n.p, c->up_disp.p, v1 - v0, r.vl, c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled,
+                              r.d_len + (size_t)g0 * kGroupSeqs, s));
     } else {
-        HIP_TRY(c->up_b.reserve(std::max<uint64_t>(r.code_bytes, 16)));
-        HIP_TRY(c->up_off.reserve(r.off.size()));
-        HIP_TRY(hipMemcpyAsync(c->up_off.p, r.off.data(), r.off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_codes, r.code_bytes, hipMemcpyHostToDevice, s));
+        const uint64_t s0 = (uint64_t)g0 * kGroupSeqs, s1 = std::min<uint64_t>(r.n_seq, (uint64_t)g1 * kGroupSeqs);
+        const uint32_t o0 = r.off[s0], o1 = r.off[s1];
+        bytes = o1 - o0;
+        HIP_TRY(c->up_b.reserve(std::max<uint64_t>(bytes, 16)));
+        HIP_TRY(c->up_off.reserve(s1 - s0 + 1));
+        HIP_TRY(hipMemcpyAsync(c->up_off.p, r.off.data() + s0, (s1 - s0 + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_codes + o0, bytes, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(c->ev_copied, s));
-        HIP_TRY(launch_tile_sequences(c->up_b.p, c->up_off.p, (uint32_t)r.n_seq, c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled, s));
+        HIP_TRY(launch_tile_sequences(c->up_b.p - o0, c->up_off.p, (uint32_t)(s1 - s0), c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled, s));
     }
-    HIP_TRY(hipEventRecord(r.ready, s));
+    HIP_TRY(hipEventRecord(ready ? ready : r.ready, s));
     HIP_TRY(hipEventSynchronize(c->ev_copied));      // the caller's buffers have been read
-    if (getenv("SWIMM_HIP_DEBUG")) {
-        const uint64_t bytes = r.kind == 0 ? r.vD : r.code_bytes;
-        fprintf(stderr, "swimm_hip: chunk of %.1f MB copied in %.2f ms (%.1f GB/s)\n", bytes / 1e6, (now_s() - t_up0) * 1e3, bytes / 1e9 / (now_s() - t_up0));
+    if (getenv("SWIMM_HIP_DEBUG"))
+        fprintf(stderr, "swimm_hip: %s of %.1f MB copied in %.2f ms (%.1f GB/s)\n", dev_groups == r.n_groups ? "chunk" : "part of a chunk", bytes / 1e6, (now_s() - t_up0) * 1e3,
+                bytes / 1e9 / (now_s() - t_up0));
+    r.groups_uploaded += dev_groups;
+    if (r.groups_uploaded >= r.n_groups) {
+        r.uploaded = true;
+        r.h_b = nullptr; r.h_n = nullptr; r.h_disp = nullptr; r.h_codes = nullptr;
+        std::vector<uint32_t>().swap(r.off);
     }
-    r.uploaded = true;
-    r.h_b = nullptr; r.h_n = nullptr; r.h_disp = nullptr; r.h_codes = nullptr;
-    std::vector<uint32_t>().swap(r.off);
     return 0;
 }
+
+int upload_chunk(swimm_hip_ctx *c, ChunkRec &r) { return upload_part(c, r, 0, r.n_groups, r.ready); }
 
 
 int ensure_uploader(swimm_hip_ctx *c)

@@ -136,10 +136,16 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    touches; no launch boundary).  -1 = default: formed when the call has two or more
  *                    queries (or streams its database in) and the database is small beside the chip; 0 = never: one launch
  *                    per pass of every query ("split", "bnd_mib" apply); 1 = always, every query joins
- *   "tall"           -1 = default: a batch of queries against a database whose launches per pass would each be bound by its longest
- *                    group's serial chain (few groups per CU) runs as ONE group-resident launch of tall workgroups (12 waves x 24
- *                    rows, one per CU, the lane-systolic tail beside it) when that is estimated to be faster; 0 = never; 1 = whenever
- *                    the 4-wave batch is not formed
+ *   "cut"            35 = default: per device group, the longest pairs leave the group (they run whole through the lane-systolic kernel
+ *                    beside the pipeline kernel, which then stops at the longest pair left) when that saves more padded pipeline
+ *                    cells than value/10 times the pairs' own cells; 0 = never
+ *   "tall"           0 = default; 1 = a batch of queries for which the 4-wave group-resident batch is not formed (its longest item would
+ *                    outlast the search) runs as ONE group-resident launch of tall workgroups (12 waves x 24 rows, one per CU, the
+ *                    lane-systolic tail beside it); -1 = when that is estimated to be faster.  Measured slower than launches per pass
+ *                    (c3 at 10 % of its size: 4 990 against 6 000 GCUPS): an A/B option, not a default
+ *   "upload_head"    1 = default: a search that streams its database in for up to four queries sends the chunk with the shortest
+ *                    sequences first, in parts of 16 MiB, 32 MiB and the rest (the chip is full 0.4 ms after the call), then the
+ *                    database in descending order; 0 = descending order, whole chunks
  *   "stack"          1 = default: short queries (up to 72 rows) of a batch share workgroups -- two to four of them stacked along the
  *                    strips of one 4-wave workgroup, each with its own score row -- instead of padding each to a launch
  *                    shape of its own; 0 = every query its own workgroups

@@ -11,6 +11,48 @@ void release_plans(swimm_hip_ctx *c)
     for (auto &kv : c->plans) { kv.second.main.release(); kv.second.tail.release(); }
     c->plans.clear();
     c->bulk.cols.clear(); c->bulk.total = 0; c->bulk.cache.clear();
+    c->cut_cols.clear(); c->cut_lane.clear();
+}
+
+// Outlier pairs.  A device group is 128 neighbours of the length-sorted database and the pipeline kernel runs it to its
+// longest member: fine in the bulk of the database, where neighbours differ by a residue or two, and a waste at its long
+// end -- Swiss-Prot's last group holds 35 000-residue titin beside sequences of 5 000, so 128 lanes run 35 000 columns for
+// the sake of a handful.  Per group (true lengths known): the pipeline kernel aligns columns [0, cut) of all 128 sequences,
+// and the pairs (lanes) that are longer than cut are ALSO lane-systolic items, whole: a prefix of an alignment never scores
+// above the alignment, so the two results merge through the score row's atomicMax, exactly.  The cut is the one that
+// minimises  128 x cut  +  rho x (cells of the pairs beyond it),  rho = opt_cut / 10: what a cell costs in the lane-systolic
+// kernel (135 instructions per 8-row column against 68, one dependent chain per wave) against a padded cell of the pipeline.
+void ensure_cuts(swimm_hip_ctx *c)
+{
+    if (c->cut_cols.size() == c->groups.size()) return;
+    const size_t n = c->groups.size();
+    c->cut_cols.resize(n); c->cut_lane.assign(n, 64);
+    const double rho = c->opt_cut * 0.1;
+    for (size_t g = 0; g < n; ++g) {
+        const GroupDesc &gd = c->groups[g];
+        c->cut_cols[g] = gd.ncols;
+        if (c->opt_cut <= 0 || (size_t)gd.seq0 + kGroupSeqs > c->seq_len.size()) continue;
+        uint32_t L[64];
+        int last = -1;                                 // the last pair that holds a sequence (the database's last group is seldom full)
+        bool sorted = true;
+        for (int l = 0; l < 64; ++l) {
+            L[l] = std::max(c->seq_len[gd.seq0 + 2 * l], c->seq_len[gd.seq0 + 2 * l + 1]);
+            if (L[l] > 0) { if (last >= 0 && L[l] < L[last]) sorted = false; last = l; }
+        }
+        if (last < 1 || !sorted) continue;             // (lengths not reported yet, a single pair, or a caller's database that is not sorted)
+        double beyond = 0, best = 128.0 * gd.ncols;    // cost with no pair cut off
+        int cut_at = 64;
+        for (int l = last; l >= 1; --l) {              // pairs l .. last leave: the pipeline runs to pair l - 1
+            beyond += 2.0 * L[l];
+            const uint32_t cols = (L[l - 1] + kChunkCols - 1) / kChunkCols * kChunkCols;
+            const double cost = 128.0 * std::max<uint32_t>(cols, kChunkCols) + rho * beyond;
+            if (cost < best * 0.97) { best = cost; cut_at = l; }       // (3 %: not for a handful of columns)
+        }
+        if (cut_at < 64) {
+            c->cut_lane[g] = (uint8_t)cut_at;
+            c->cut_cols[g] = std::max<uint32_t>((L[cut_at - 1] + kChunkCols - 1) / kChunkCols * kChunkCols, kChunkCols);
+        }
+    }
 }
 
 int regs_to_waves_per_simd(int regs)
@@ -124,7 +166,7 @@ void bulk_cols_of(const swimm_hip_ctx *c, const Range &rg, BulkCols &b)
     const std::vector<uint8_t> is_tail = pick_tail(c, rg);
     b.cols.clear(); b.total = 0; b.cache.clear();
     for (uint32_t g = rg.g0; g < rg.g1; ++g)
-        if (!is_tail[g - rg.g0]) { b.cols.push_back(c->groups[g].ncols); b.total += c->groups[g].ncols; }
+        if (!is_tail[g - rg.g0]) { b.cols.push_back(bulk_cols(c, g)); b.total += bulk_cols(c, g); }
     std::sort(b.cols.begin(), b.cols.end(), std::greater<uint32_t>());
 }
 
@@ -294,7 +336,7 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
         for (uint32_t idx : bins[w]) {
             const WorkUnit &u = units[idx];
             const GroupDesc &gd = c->groups[u.group];
-            Item it{}; it.db = gd.db; it.ncols = gd.ncols; it.seq0 = gd.seq0; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = u.bnd_off;
+            Item it{}; it.db = gd.db; it.ncols = u.ncols; it.seq0 = gd.seq0; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = u.bnd_off;
             items.push_back(it);
         }
         chunks[w] = (uint32_t)(load[w] / kChunkCols);
@@ -309,7 +351,7 @@ int build_plan(swimm_hip_ctx *c, const std::vector<WorkUnit> &units, int n_wg, P
     for (uint32_t idx : order) {
         const WorkUnit &u = units[idx];
         const GroupDesc &gd = c->groups[u.group];
-        Item it{}; it.db = gd.db; it.ncols = gd.ncols; it.seq0 = gd.seq0; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = before;
+        Item it{}; it.db = gd.db; it.ncols = u.ncols; it.seq0 = gd.seq0; it.half = u.half; it.out_slot = u.out_slot; it.bnd_off = before;
         before += u.ncols;
         sorted.push_back(it);
         pl.queue_cols.push_back(u.ncols);
@@ -376,7 +418,8 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> 
     if (c->opt_tail_mode == 1) { std::fill(is_tail.begin(), is_tail.end(), 1); return is_tail; }   // always
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->groups[rg.g0 + a].ncols > c->groups[rg.g0 + b].ncols; });
+    // (a group counts with the columns the pipeline kernel would align: its outlier pairs are lane-systolic items anyway)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bulk_cols(c, rg.g0 + a) > bulk_cols(c, rg.g0 + b); });
     uint64_t rest = rg.cols;
     // The yardstick is the load of a CU, however many workgroups share it -- and the lane-systolic kernel must stay a side
     // show: it aligns a cell at 1.5x the pipeline kernel's instructions and, beside the bulk waves, at a tenth of its rate,
@@ -390,14 +433,15 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> 
     double tail_cells = 0;
     for (uint32_t g : order) {
         const GroupDesc &gd = c->groups[rg.g0 + g];
+        const uint32_t gcols = bulk_cols(c, rg.g0 + g);
         const double mean = (double)rest / c->num_cu;
-        if ((double)gd.ncols <= c->opt_tail_frac * 0.01 * mean) break;
+        if ((double)gcols <= c->opt_tail_frac * 0.01 * mean) break;
         double cells = 0;
         for (uint32_t l = 0; l < 64; ++l) cells += 2.0 * std::max(c->seq_len[gd.seq0 + 2 * l], c->seq_len[gd.seq0 + 2 * l + 1]);
         if (cells == 0) cells = 128.0 * gd.ncols;          // (a chunk whose true lengths the re-tile kernel has yet to report: the group's)
         // (a group longer than a whole CU's mean load would hold up every launch it is part of: for those the cap is 8 % --
         // c3 at 10 % of its size, 423 groups of which most are that long: 2 970 GCUPS under the 2.5 % cap, 3 680 under 8 %)
-        if (capped && tail_cells + cells > ((double)gd.ncols > mean ? std::max(cap, (double)rg.cols * kGroupSeqs * 0.08) : cap)) break;
+        if (capped && tail_cells + cells > ((double)gcols > mean ? std::max(cap, (double)rg.cols * kGroupSeqs * 0.08) : cap)) break;
         tail_cells += cells;
         is_tail[g] = 1;
         rest -= gd.ncols;
@@ -413,12 +457,17 @@ int make_db_plan(swimm_hip_ctx *c, Mode mode, int n_wg, bool no_tail, const Rang
     uint64_t bnd_cols = 0;
     const uint64_t col0 = rg.g0 < c->group_col_off.size() ? c->group_col_off[rg.g0] : 0;
     if (mode != Mode::I32) {
+        const bool cuts = !no_tail && exact_lengths && c->opt_tail_mode != 2;       // (a launch that takes every group through the pipeline kernel has no lane-systolic kernel beside it)
+        if (cuts) ensure_cuts(c);
         std::vector<uint8_t> is_tail = pick_tail(c, rg);
         if (no_tail) std::fill(is_tail.begin(), is_tail.end(), 0);   // every group through the pipeline kernel
         for (uint32_t g = rg.g0; g < rg.g1; ++g) {
             const GroupDesc &gd = c->groups[g];
-            if (!is_tail[g - rg.g0]) { units.push_back(WorkUnit{g, 0, 0, gd.ncols, c->group_col_off[g] - col0}); continue; }
-            for (uint32_t l = 0; l < 64; ++l) {
+            if (!is_tail[g - rg.g0]) {
+                units.push_back(WorkUnit{g, 0, 0, cuts ? bulk_cols(c, g) : gd.ncols, c->group_col_off[g] - col0});
+                if (!cuts || c->cut_lane[g] >= 64) continue;
+            }
+            for (uint32_t l = is_tail[g - rg.g0] ? 0 : c->cut_lane[g]; l < 64; ++l) {
                 // a pair only runs to the end of its longer member, not to the end of the group (when the lengths are
                 // already known: a chunk that is still streaming in runs to the end of its group -- padding scores 0)
                 const uint32_t len = exact_lengths ? std::max(c->seq_len[gd.seq0 + 2 * l], c->seq_len[gd.seq0 + 2 * l + 1]) : gd.ncols;

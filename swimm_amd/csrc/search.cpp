@@ -228,7 +228,7 @@ int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::ve
             pass_total += passes; bnd_cols += need; max_passes = std::max(max_passes, passes);
         }
         const size_t need_prog = max_passes > 1 ? (size_t)pass_total * ll.n : 0;
-        if (sc.bnd[0].cap < bnd_cols || sc.bnd[1].cap < bnd_cols || sc.queue.cap < pass_total || sc.prog.cap < need_prog || sc.lq.cap < lq.size())
+        if (sc.bnd[0].cap < bnd_cols || sc.bnd[1].cap < bnd_cols || sc.queue.cap < pass_total || sc.prog.cap < need_prog)
             return fail("internal: lane scratch too small (%zu/%llu columns, %zu/%zu counters, %zu/%zu queries)", sc.bnd[0].cap, (unsigned long long)bnd_cols, sc.prog.cap,
                         need_prog, sc.lq.cap, lq.size());
         // workgroups per (query, pass): the chip's budget dealt evenly (every (query, pass) walks the same items); a launch
@@ -242,13 +242,19 @@ int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::ve
             for (size_t i = 0; i < lq.size(); ++i)
                 if (ps < lq[i].passes)
                     for (uint32_t k = 0; k < per; ++k) block_map.push_back((uint32_t)(i << 8) | ps);
-        if (sc.block_map.cap < block_map.size()) return fail("internal: lane scratch too small (%zu/%zu workgroups)", sc.block_map.cap, block_map.size());
-        if (list_copy(c, sc.lq.p, lq.data(), lq.size() * sizeof(LaneQ)) || list_copy(c, sc.block_map.p, block_map.data(), block_map.size() * sizeof(uint32_t)) || list_sync(c)) return 1;
+        // (every launch of the search has its own region of the two tables: a scratch serves one range after the other of a
+        // database that streams in, and the next range's tables must not overwrite what a launch in flight still reads)
+        if (sc.lq.cap < sc.lq_used + lq.size() || sc.block_map.cap < sc.bm_used + block_map.size())
+            return fail("internal: lane scratch too small (%zu/%zu queries, %zu/%zu workgroups of all launches)", sc.lq.cap, sc.lq_used + lq.size(), sc.block_map.cap, sc.bm_used + block_map.size());
+        LaneQ *const d_lq = sc.lq.p + sc.lq_used;
+        uint32_t *const d_bm = sc.block_map.p + sc.bm_used;
+        sc.lq_used += lq.size(); sc.bm_used += block_map.size();
+        if (list_copy(c, d_lq, lq.data(), lq.size() * sizeof(LaneQ)) || list_copy(c, d_bm, block_map.data(), block_map.size() * sizeof(uint32_t)) || list_sync(c)) return 1;
         LaneParams p{};
         p.items = ll.items.p;
         p.n_items = ll.n;
-        p.lq = sc.lq.p;
-        p.block_map = sc.block_map.p;
+        p.lq = d_lq;
+        p.block_map = d_bm;
         p.queue = sc.queue.p;
         p.prog = sc.prog.p;
         p.prof = c->d_prof.p;
@@ -265,17 +271,18 @@ int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::ve
         c->launches++;
         c->cells += ll.cell_cols * (uint64_t)rows_pass * pass_total * (mode == Mode::PK16 ? 2 : 1);
         at = end;
-        // (a further launch of the batch reuses the scratch: the tables above travel on the list stream, so this stream has to
-        // have taken the launch before they are overwritten -- rare: more than num_cu chained passes in one batch)
-        if (at < qs.size()) HIP_TRY(hipStreamSynchronize(st));
+
     }
     return 0;
 }
 
 // scratch of a lane-systolic launch of `queries` queries with `pass_total` passes in all over `items` items; bnd_cols:
 // boundary columns of its multi-pass queries together (each: the list's columns + 64)
-int reserve_lane_scratch(swimm_hip_ctx *c, LaneScratch &sc, size_t list_cols, size_t items, size_t pass_total, size_t queries, size_t multi_pass_queries)
+int reserve_lane_scratch(swimm_hip_ctx *c, LaneScratch &sc, size_t list_cols, size_t items, size_t pass_total, size_t queries, size_t multi_pass_queries, size_t launches)
 {
+    // (`launches`: how often the scratch is used in one search -- once per range; a batch that exceeds the chip is cut further)
+    launches = std::max<size_t>(1, launches) + pass_total / std::max(1, c->num_cu) + queries / 4096 + 1;
+    sc.lq_used = sc.bm_used = 0;
     size_t bnd_cols = multi_pass_queries * (list_cols + 64);
     bnd_cols = std::min<size_t>(bnd_cols, std::max<size_t>(kLaneBndColsMax, list_cols + 64));
     pass_total = std::min<size_t>(pass_total, 4096 + 255);
@@ -286,8 +293,8 @@ int reserve_lane_scratch(swimm_hip_ctx *c, LaneScratch &sc, size_t list_cols, si
         HIP_TRY(sc.bnd[1].reserve(bnd_cols));
     }
     HIP_TRY(sc.prog.reserve(std::max<size_t>(1, multi_pass_queries ? items * std::min<size_t>(pass_total, (size_t)c->num_cu + 255) : 1)));
-    HIP_TRY(sc.lq.reserve(std::max<size_t>(1, queries)));
-    HIP_TRY(sc.block_map.reserve((size_t)c->num_cu * 6 + 4096));
+    HIP_TRY(sc.lq.reserve(std::max<size_t>(1, queries) * launches));
+    HIP_TRY(sc.block_map.reserve(((size_t)c->num_cu * 6 + 4096) * launches));
     return 0;
 }
 
@@ -499,15 +506,25 @@ int SearchRun::layout_ranges()
         // The chunk that travels first goes in parts -- 16 MiB, 32 MiB, the rest -- so that the first launch has its data
         // after 0.4 ms instead of the 2 ms a whole 96 MiB chunk takes on the link (the head part is the chunk's end with the
         // longest sequences when the database travels in descending order).
+        // ... and which chunk is that?  Not the one with the longest sequences: its groups are few (a 96 MiB chunk of 5 000-residue
+        // sequences is 26 groups per 16 MiB) and each is a chain of 15 ms, so the head launches would hold three streams with
+        // a few dozen workgroups while the chunks behind them wait for a stream (measured: 33.5 ms against 31.0 without parts).
+        // The chunk with the SHORTEST sequences goes first -- thousands of groups per part: the chip is full 0.4 ms after the
+        // call and its launches end as soon as their work is done -- then the database in descending order as before: the
+        // long chains start with the second chunk, 4 ms in, and the last range is still one of short sequences.
+        std::vector<size_t> chunk_order;
+        for (size_t i = 0; i < nc; ++i) chunk_order.push_back(descending ? nc - 1 - i : i);
+        const bool short_first = descending && nc >= 3 && c->opt_upload_head && qn <= 4;
+        if (short_first) { chunk_order.insert(chunk_order.begin(), chunk_order.back()); chunk_order.pop_back(); }
         size_t n_part_ev = 0;
         for (size_t i = 0; i < nc; ++i) {
-            const size_t ci = descending ? nc - 1 - i : i;
+            const size_t ci = chunk_order[i];
             const ChunkRec &r = c->chunks[ci];
             const uint64_t bytes = r.kind == 0 ? r.vD : r.code_bytes;
             bool ascending = true;
             if (r.kind == 0 && !r.uploaded)
                 for (uint32_t v = 1; v < r.group_count; ++v) ascending = ascending && r.h_disp[v] >= r.h_disp[v - 1];
-            if (i == 0 && !r.uploaded && r.groups_uploaded == 0 && ascending && bytes >= ((uint64_t)56 << 20) && r.n_groups >= 16 && qn <= 4) {
+            if (i == 0 && short_first && !r.uploaded && r.groups_uploaded == 0 && ascending && bytes >= ((uint64_t)56 << 20) && r.n_groups >= 16) {
                 const uint64_t heads[2] = {(uint64_t)16 << 20, (uint64_t)32 << 20};
                 uint32_t edge = descending ? r.n_groups : 0;      // the groups still to be dealt: [0, edge) or [edge, n)
                 for (int h = 0; h < 2; ++h) {
@@ -548,6 +565,10 @@ int SearchRun::layout_ranges()
                 rg.g0 = std::min(rg.g0, r.group0 + pt.g0); rg.g1 = std::max(rg.g1, r.group0 + pt.g1); rg.cols += part_cols(pt);
                 t_up += up_s(pt); work += dp_s(pt);
                 ++i;
+                if (i < np) {                              // (a range is a run of consecutive device groups)
+                    const uint32_t n0 = c->chunks[up_order[i].chunk].group0 + up_order[i].g0, n1 = c->chunks[up_order[i].chunk].group0 + up_order[i].g1;
+                    if (n0 != rg.g1 && n1 != rg.g0) break;
+                }
             } while (i < np && t_up + up_s(up_order[i]) <= t_gpu);
             t_gpu = std::max(t_gpu, t_up) + work;
             ranges.push_back(rg);
@@ -582,6 +603,10 @@ int SearchRun::plan_queries()
     for (const GroupDesc &g : c->groups) longest_cols = std::max(longest_cols, g.ncols);
     if (c->opt_tail_mode != 2 && main_mode != Mode::I32)
         lane_room = c->opt_tail_mode == 1 || (double)longest_cols > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
+    if (c->opt_tail_mode != 2 && main_mode != Mode::I32) {          // outlier pairs run through the lane-systolic kernel as well
+        ensure_cuts(c);
+        for (size_t g = 0; g < c->cut_lane.size() && !lane_room; ++g) lane_room = c->cut_lane[g] < 64;
+    }
     if (c->opt_lane_room >= 0) lane_room = c->opt_lane_room != 0 && main_mode != Mode::I32;
     if (dbg) fprintf(stderr, "swimm_hip: ranges laid out, uploader started %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     qps.assign(qn, QueryPlan{});
@@ -807,7 +832,10 @@ int SearchRun::size_buffers()
                 for (uint32_t g = ranges[ri].g0; g < ranges[ri].g1; ++g) {
                     longest_all = std::max(longest_all, c->groups[g].ncols);
                     if (is_tail[g - ranges[ri].g0]) { t_items += 64; t_cols += (size_t)64 * c->groups[g].ncols; }
-                    else longest_main = std::max(longest_main, c->groups[g].ncols);
+                    else {
+                        longest_main = std::max(longest_main, c->groups[g].ncols);
+                        if (g < c->cut_lane.size() && c->cut_lane[g] < 64) { t_items += 64 - c->cut_lane[g]; t_cols += (size_t)(64 - c->cut_lane[g]) * c->groups[g].ncols; }   // outlier pairs
+                    }
                 }
                 tail_items = std::max(tail_items, t_items);
                 tail_cols = std::max(tail_cols, t_cols);
@@ -865,14 +893,14 @@ int SearchRun::size_buffers()
                 passes_of[cls] += ps; queries_of[cls]++; multi += ps > 1;
             }
             tail_lanes = tail_items > 0 ? 1 + (queries_of[1] > 0) + (queries_of[2] > 0) : 1;
-            if (tail_items > 0 && reserve_lane_scratch(c, c->tail_scratch, tail_cols, tail_items, passes_of[0], queries_of[0], multi)) return 1;
+            if (tail_items > 0 && reserve_lane_scratch(c, c->tail_scratch, tail_cols, tail_items, passes_of[0], queries_of[0], multi, ranges.size())) return 1;
             for (int i = 0; i < 2; ++i) {
                 if (tail_items == 0 || queries_of[i + 1] == 0) continue;
                 if (!c->stream_t[i]) {
                     HIP_TRY(hipStreamCreate(&c->stream_t[i]));
                     HIP_TRY(hipEventCreateWithFlags(&c->ev_tail_t[i], hipEventDisableTiming));
                 }
-                if (reserve_lane_scratch(c, c->tail_scratch_t[i], tail_cols, tail_items, passes_of[i + 1], queries_of[i + 1], 0)) return 1;
+                if (reserve_lane_scratch(c, c->tail_scratch_t[i], tail_cols, tail_items, passes_of[i + 1], queries_of[i + 1], 0, ranges.size())) return 1;
             }
             if (dbg && tail_items) fprintf(stderr, "swimm_hip: tail of %zu items: %zu / %zu / %zu queries with 8 / 4 / 2 rows per lane, %zu chained passes in all\n", tail_items, queries_of[0], queries_of[1], queries_of[2], passes_of[0]);
         }
@@ -1173,6 +1201,7 @@ int SearchRun::promotion_ladder()
             LaneList ll;
             ll.items.p = c->d_rerun_items.p; ll.items.cap = c->d_rerun_items.cap;
             ll.n = (uint32_t)items.size(); ll.cols = cols; ll.cell_cols = cols;
+            c->rerun_scratch.lq_used = c->rerun_scratch.bm_used = 0;      // (stream 3 has drained just above: the previous re-run's tables are free)
             const int rc = run_lane_batch(c, mode, kLaneRows, std::vector<LaneQuery>{LaneQuery{qm[q], qps[q].prof_off, qps[q].mpad, (uint64_t)q * S}}, ll, c->stream3, c->rerun_scratch);
             ll.items.p = nullptr; ll.items.cap = 0;           // borrowed
             return rc;

@@ -483,6 +483,10 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "rotate")) {
         c->opt_rotate = value != 0;
+    } else if (!strcmp(key, "cut")) {
+        if (value < 0 || value > 1000) return fail("cut must be 0 (never) .. 1000 (tenths: cost of a lane-systolic cell against a padded pipeline cell)");
+        c->opt_cut = value;
+        release_plans(c);
     } else if (!strcmp(key, "tall")) {
         if (value < -1 || value > 1) return fail("tall must be -1 (auto), 0 or 1");
         c->opt_tall = value;
@@ -512,6 +516,8 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "lazy_upload")) {
         c->opt_lazy_upload = value != 0;
+    } else if (!strcmp(key, "upload_head")) {
+        c->opt_upload_head = value != 0;
     } else if (!strcmp(key, "upload_piece_kib")) {
         if (value < 16) return fail("upload_piece_kib must be >= 16");
         c->opt_upload_piece_kib = value;

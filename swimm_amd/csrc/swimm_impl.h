@@ -108,8 +108,9 @@ struct DbPlan {          // per (mode, n_wg): main partition + the groups handed
 struct LaneScratch {
     DevBuf<unsigned long long> bnd[2];
     DevBuf<uint32_t> queue, prog;
-    DevBuf<LaneQ> lq;                   // the launch's queries
-    DevBuf<uint32_t> block_map;         // (query, pass) of every workgroup
+    DevBuf<LaneQ> lq;                   // the launches' queries ...
+    DevBuf<uint32_t> block_map;         // ... and (query, pass) of every workgroup: every launch of a search takes a region of its own
+    size_t lq_used = 0, bm_used = 0;    // (a scratch serves one range after the other; the tables of a launch must outlive it)
     void release() { bnd[0].release(); bnd[1].release(); queue.release(); prog.release(); lq.release(); block_map.release(); }
 };
 
@@ -173,6 +174,7 @@ struct swimm_hip_ctx {
     hipEvent_t ev_copied = nullptr;
     DevBuf<uint8_t> up_b; DevBuf<uint16_t> up_n; DevBuf<uint32_t> up_disp, up_gcols, up_off; DevBuf<uint64_t> up_goff;   // upload scratch, reused chunk after chunk
     int opt_upload_piece_kib = 98304;   // lazy_upload: chunks and slabs larger than this are recorded in pieces of about this size (96 MiB, the reference's chunk size)
+    int opt_upload_head = 1;            // lazy_upload, up to four queries: the chunk with the shortest sequences travels first, in parts of 16 MiB, 32 MiB and the rest (0: the database in descending order, whole chunks)
     int opt_lazy_upload = 0;            // 1: add_chunk / add_sequences record the caller's buffers, the first search streams them in
     hipStream_t stream3 = nullptr;      // promotion re-runs
     hipEvent_t ev_ready = nullptr, ev_tail3 = nullptr;
@@ -195,7 +197,10 @@ struct swimm_hip_ctx {
     bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
     DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
     DevBuf<uint32_t> d_wave_out;        // stacks of short queries: per (stack, wave) the first element of the wave's member's score row
-    int opt_tall = -1;                  // group-resident batches of TALL workgroups (12 x 24 rows, one per CU) beside the tail kernels for a database whose per-pass launches would be chain-bound: -1 = by estimate, 0 never, 1 whenever the 4-wave batch is not formed
+    int opt_tall = 0;                   // group-resident batches of TALL workgroups (12 x 24 rows, one per CU) beside the tail kernels for a database whose per-pass launches would be chain-bound: 0 = never (default: measured slower than launches per pass beside ONE lane-systolic launch for all queries, c3 at 10 % 4 990 vs 6 000 GCUPS), -1 = by estimate, 1 = whenever the 4-wave batch is not formed
+    int opt_cut = 35;                   // outlier pairs: a group's longest pairs leave it for the lane-systolic kernel when that saves the pipeline kernel more padded cells than opt_cut/10 x the pairs' own (0 = never)
+    std::vector<uint32_t> cut_cols;     // per group: the columns the pipeline kernel aligns (<= ncols; the pairs that are longer are lane-systolic items as well)
+    std::vector<uint8_t> cut_lane;      // per group: the first lane (pair) that is an outlier (64 = none)
     int opt_stack = 1;                  // 1: short one-pass queries of a batch share workgroups (several queries stacked along the strips)
     int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
     std::vector<hipEvent_t> launch_ev;  // pairs (before, after), grown on demand
@@ -365,6 +370,8 @@ int list_copy(swimm_hip_ctx *c, void *dst, const void *src, size_t bytes);
 int list_sync(swimm_hip_ctx *c);
 Range whole_range(const swimm_hip_ctx *c);
 std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg);
+void ensure_cuts(swimm_hip_ctx *c);
+inline uint32_t bulk_cols(const swimm_hip_ctx *c, uint32_t g) { return g < c->cut_cols.size() ? c->cut_cols[g] : c->groups[g].ncols; }
 double lpt_imbalance(BulkCols &b, int n_wg);
 void bulk_cols_of(const swimm_hip_ctx *c, const Range &rg, BulkCols &b);
 double plan_imbalance(swimm_hip_ctx *c, int n_wg);
@@ -398,7 +405,7 @@ int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl
 int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st, bool allow_split, DevBuf<uint2> &bnd);
 int lane_rows_for(const swimm_hip_ctx *c, uint32_t m);
 int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::vector<LaneQuery> &qs, const LaneList &ll, hipStream_t st, LaneScratch &sc);
-int reserve_lane_scratch(swimm_hip_ctx *c, LaneScratch &sc, size_t list_cols, size_t items, size_t pass_total, size_t queries, size_t multi_pass_queries);
+int reserve_lane_scratch(swimm_hip_ctx *c, LaneScratch &sc, size_t list_cols, size_t items, size_t pass_total, size_t queries, size_t multi_pass_queries, size_t launches = 1);
 int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_out);
 
 }  // namespace swimm_impl

@@ -134,6 +134,27 @@ def test_streamed_ranges_rotating_tail_launches_then_promotion():
     run_case(seqs, queries, opts=dict(opts, f16=0), max_chunk=60000)
 
 
+def test_outlier_pairs_leave_their_group():
+    """Groups whose last few sequences are far longer than the rest (Swiss-Prot's long end): the pipeline kernel stops at the
+    longest pair that stays, the outlier pairs run whole through the lane-systolic kernel as well, and the two results merge
+    in the score row -- one-pass and multi-pass queries, per-pass and group-resident launches, with hits that lie wholly
+    beyond the cut, across it, and before it."""
+    rng = np.random.default_rng(1234)
+    q1, q2, q3 = rnd(rng, 90), rnd(rng, 700), rnd(rng, 1500)
+    seqs = [rnd(rng, int(n)) for n in rng.integers(150, 400, 900)]
+    # outliers: 3 to 40 times their neighbours' length, with copies of the queries planted at the start, across column ~400 and at the far end
+    for k, n in enumerate([1200, 1300, 2500, 2600, 6000, 6100, 15000, 15001]):
+        s = rnd(rng, n)
+        src = (q1, q2, q3)[k % 3]
+        at = (0, 380, n - len(src) - 7)[k % 3] if n > len(src) + 400 else 0
+        s[at:at + len(src)] = src
+        seqs.append(s)
+    seqs += [rnd(rng, int(n)) for n in rng.integers(600, 700, 130)]          # a full group of medium sequences between bulk and outliers
+    for opts in ({}, {"cut": 0}, {"cut": 5}, {"resident": 0}, {"tall": 1}, {"tail_mode": 2}, {"f16": 0}, {"lazy_upload": 1, "upload_piece_kib": 64}):
+        want, stats = run_case(seqs, [q1, q2, q3], matrix="blosum50", opts=opts, max_chunk=300000)
+    assert want.max() > 2048
+
+
 def test_mass_promotion():
     """a family of 66 000 near-copies of the query: every alignment leaves the binary16 range (>= 2048), more than
     any fixed-size list would hold; plus 40 W-runs that also leave int16.  All of them come back exact."""

@@ -203,7 +203,7 @@ static const uint64_t kLaneBndColsMax = (uint64_t)1 << 30;
 // pass waits for the one before it), ascending in pass so that producers are dispatched first; 4 waves per workgroup.
 int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::vector<LaneQuery> &qs, const LaneList &ll, hipStream_t st, LaneScratch &sc)
 {
-    if (ll.n == 0 || qs.empty()) return 0;
+    if (qs.empty() || (ll.n == 0 && qs[0].n_items == 0)) return 0;
     const int rows_pass = 64 * rows_per_lane;
     size_t at = 0;
     while (at < qs.size()) {
@@ -212,36 +212,42 @@ int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::ve
         uint32_t pass_total = 0, max_passes = 1;
         uint64_t bnd_cols = 0;
         size_t end = at;
+        size_t prog_total = 0;
+        uint64_t cells = 0;
         for (; end < qs.size(); ++end) {
             const uint32_t passes = (qs[end].m + rows_pass - 1) / rows_pass;
+            const uint32_t n_q = qs[end].n_items ? qs[end].n_items : ll.n;
+            const uint64_t cols_q = qs[end].n_items ? qs[end].cols : ll.cols;
             if (passes > 255) return fail("query of %u rows needs %u chained lane passes (255 at most)", qs[end].m, passes);
             if ((int)passes > c->num_cu) return fail("query of %u rows needs %u chained passes, more than the %d CUs", qs[end].m, passes, c->num_cu);
             if (passes > 1 && rows_per_lane != kLaneRows) return fail("internal: a multi-pass query in a short-lane launch");
-            const uint64_t need = passes > 1 ? ll.cols + 64 : 0;
+            const uint64_t need = passes > 1 ? cols_q + 64 : 0;
             // (launches with chained passes must be resident as a whole: one workgroup per (query, pass) at least, one per CU at most)
             const uint32_t limit = rows_per_lane == kLaneRows ? (uint32_t)c->num_cu : 4096u;
             if (end > at && (pass_total + passes > limit || bnd_cols + need > kLaneBndColsMax)) break;
             LaneQ d{};
             d.prof_off = qs[end].prof_off; d.out_off = qs[end].out_off; d.bnd0 = bnd_cols; d.prof_stride = qs[end].prof_stride; d.m = qs[end].m;
-            d.passes = passes; d.queue0 = pass_total; d.prog0 = pass_total;
+            d.passes = passes; d.queue0 = pass_total; d.prog0 = (uint32_t)prog_total; d.items0 = qs[end].items0; d.n_items = n_q;
+            if (prog_total + (size_t)passes * n_q > 0xFFFFFFF0ull) return fail("lane-systolic launch: more than 2^32 progress counters");
             lq.push_back(d);
             pass_total += passes; bnd_cols += need; max_passes = std::max(max_passes, passes);
+            prog_total += (size_t)passes * n_q;
+            cells += cols_q * (uint64_t)rows_pass * passes;
         }
-        const size_t need_prog = max_passes > 1 ? (size_t)pass_total * ll.n : 0;
+        const size_t need_prog = max_passes > 1 ? prog_total : 0;
         if (sc.bnd[0].cap < bnd_cols || sc.bnd[1].cap < bnd_cols || sc.queue.cap < pass_total || sc.prog.cap < need_prog)
             return fail("internal: lane scratch too small (%zu/%llu columns, %zu/%zu counters, %zu/%zu queries)", sc.bnd[0].cap, (unsigned long long)bnd_cols, sc.prog.cap,
                         need_prog, sc.lq.cap, lq.size());
         // workgroups per (query, pass): the chip's budget dealt evenly (every (query, pass) walks the same items); a launch
         // without chained passes may ask for more than the chip holds at once
         const uint32_t budget = max_passes > 1 ? (uint32_t)c->num_cu : (uint32_t)c->num_cu * 6;
-        uint32_t per = std::max<uint32_t>(1, budget / pass_total);
-        per = (uint32_t)std::min<uint64_t>(per, (ll.n + 3) / 4);
+        const uint32_t per = std::max<uint32_t>(1, budget / pass_total);
         std::vector<uint32_t> block_map;
         block_map.reserve((size_t)per * pass_total);
         for (uint32_t ps = 0; ps < max_passes; ++ps)
             for (size_t i = 0; i < lq.size(); ++i)
                 if (ps < lq[i].passes)
-                    for (uint32_t k = 0; k < per; ++k) block_map.push_back((uint32_t)(i << 8) | ps);
+                    for (uint32_t k = 0; k < std::min<uint32_t>(per, (lq[i].n_items + 3) / 4); ++k) block_map.push_back((uint32_t)(i << 8) | ps);
         // (every launch of the search has its own region of the two tables: a scratch serves one range after the other of a
         // database that streams in, and the next range's tables must not overwrite what a launch in flight still reads)
         if (sc.lq.cap < sc.lq_used + lq.size() || sc.block_map.cap < sc.bm_used + block_map.size())
@@ -252,7 +258,6 @@ int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::ve
         if (list_copy(c, d_lq, lq.data(), lq.size() * sizeof(LaneQ)) || list_copy(c, d_bm, block_map.data(), block_map.size() * sizeof(uint32_t)) || list_sync(c)) return 1;
         LaneParams p{};
         p.items = ll.items.p;
-        p.n_items = ll.n;
         p.lq = d_lq;
         p.block_map = d_bm;
         p.queue = sc.queue.p;
@@ -269,7 +274,7 @@ int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::ve
         if (max_passes > 1) HIP_TRY(hipMemsetAsync(sc.prog.p, 0, need_prog * sizeof(uint32_t), st));
         HIP_TRY(launch_lane(mode, rows_per_lane, (int)block_map.size(), p, st));
         c->launches++;
-        c->cells += ll.cell_cols * (uint64_t)rows_pass * pass_total * (mode == Mode::PK16 ? 2 : 1);
+        c->cells += cells * (mode == Mode::PK16 ? 2 : 1);
         at = end;
 
     }
@@ -370,6 +375,7 @@ struct SearchRun {
     int size_buffers();
     int issue();
     int promotion_ladder();
+    int ladder_rung(const std::vector<uint32_t> &batch, int thr, Mode mode);
     int drain();
     int run(uint64_t *slots_out)
     {
@@ -1157,67 +1163,86 @@ int SearchRun::issue()
     return 0;
 }
 
+// Promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher): f16 results >= 2048 are
+// re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; every re-run is a lane-systolic item (one wave per
+// alignment).  The queries climb the ladder in two batches -- the longer half (issued first: done while the shorter half's
+// kernels still run), then the rest -- and a batch climbs together: one scan per query into a shared list, ONE copy back,
+// ONE lane-systolic launch for all the batch's re-runs.  (One query at a time, round 2's way, was a chain of its own: c3 at
+// a tenth of its size spent 17 x 2.2 ms on the int16 re-runs of 17 queries, a handful of 3 000-column alignments each, behind
+// a tail launch that now ends for all queries at once.)
 int SearchRun::promotion_ladder()
 {
     t_issued = now_s();
-    // promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher):
-    // f16 results >= 2048 are re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; each
-    // re-run is a lane-systolic item (one wave per alignment), issued on stream 3 as soon as the query's own
-    // kernels are done
-    if (main_mode != Mode::I32) {
-        const uint32_t cap = (uint32_t)std::min<uint64_t>(S, 0xFFFFFFFEull);   // list capacity = all slots: no query can overflow it
-        std::vector<uint32_t> list;
-        auto collect = [&](uint32_t q, int thr, std::vector<uint32_t> &out) -> int {
-            int32_t *row = c->d_scores.p + (size_t)q * S;
-            uint32_t *d_count = c->d_satlist.p + cap;
-            HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream3));
-            HIP_TRY(launch_collect_saturated(row, S, thr, c->d_satlist.p, d_count, cap, c->stream3));
-            uint32_t count = 0;
-            HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream3));
-            HIP_TRY(hipStreamSynchronize(c->stream3));
-            if (count > cap) return fail("more than %u alignments of query %u left the %s range: use force_i32", cap, q, thr == 2048 ? "f16" : "int16");
-            out.resize(count);
-            if (count) {
-                HIP_TRY(hipMemcpyAsync(out.data(), c->d_satlist.p, count * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream3));
-                HIP_TRY(hipStreamSynchronize(c->stream3));
-            }
-            return 0;
-        };
-        auto rerun = [&](uint32_t q, Mode mode, std::vector<LaneItem> &items) -> int {
-            if (items.empty()) return 0;
-            std::stable_sort(items.begin(), items.end(), [](const LaneItem &a, const LaneItem &b) { return a.ncols > b.ncols; });
-            uint64_t cols = 0;
-            for (LaneItem &it : items) { it.bnd_off = (uint32_t)cols; cols += it.ncols; }
-            const int rpasses = (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows));
-            if (items.size() > c->d_rerun_items.cap || (rpasses > 1 && cols + 64 > c->rerun_scratch.bnd[0].cap) ||
-                items.size() * (size_t)rpasses > c->rerun_scratch.prog.cap) {
-                // growing a buffer frees the old one, which waits for the whole device: rare (first big batch)
-                HIP_TRY(hipDeviceSynchronize());
-                HIP_TRY(c->d_rerun_items.reserve(items.size() * 2));
-                if (reserve_lane_scratch(c, c->rerun_scratch, cols * 2, items.size() * 2, rpasses, 1, rpasses > 1 ? 1 : 0)) return 1;
-            }
-            HIP_TRY(hipMemcpyAsync(c->d_rerun_items.p, items.data(), items.size() * sizeof(LaneItem), hipMemcpyHostToDevice, c->stream3));
-            HIP_TRY(hipStreamSynchronize(c->stream3));       // `items` is a host temporary
-            LaneList ll;
-            ll.items.p = c->d_rerun_items.p; ll.items.cap = c->d_rerun_items.cap;
-            ll.n = (uint32_t)items.size(); ll.cols = cols; ll.cell_cols = cols;
-            c->rerun_scratch.lq_used = c->rerun_scratch.bm_used = 0;      // (stream 3 has drained just above: the previous re-run's tables are free)
-            const int rc = run_lane_batch(c, mode, kLaneRows, std::vector<LaneQuery>{LaneQuery{qm[q], qps[q].prof_off, qps[q].mpad, (uint64_t)q * S}}, ll, c->stream3, c->rerun_scratch);
-            ll.items.p = nullptr; ll.items.cap = 0;           // borrowed
-            return rc;
-        };
-        for (uint32_t k = 0; k < qn; ++k) {
-            const uint32_t q = qn - 1 - k;
-            const long bound = (long)qm[q] * c->max_pos;     // no alignment of this query can score more
-            if (!((main_mode == Mode::F16 && bound >= 2048) || bound >= 32767)) continue;
+    if (main_mode == Mode::I32) return 0;
+    std::vector<uint32_t> climbers;                          // longest first
+    for (uint32_t k = 0; k < qn; ++k) {
+        const uint32_t q = qn - 1 - k;
+        const long bound = (long)qm[q] * c->max_pos;         // no alignment of this query can score more
+        if ((main_mode == Mode::F16 && bound >= 2048) || bound >= 32767) climbers.push_back(q);
+    }
+    const size_t half = climbers.size() >= 4 ? (climbers.size() + 1) / 2 : climbers.size();
+    for (size_t b0 = 0; b0 < climbers.size(); b0 += std::max<size_t>(half, 1)) {
+        const std::vector<uint32_t> batch(climbers.begin() + b0, climbers.begin() + std::min(climbers.size(), b0 + half));
+        for (uint32_t q : batch) {
             HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_query[2 * q], 0));
             HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_query[2 * q + 1], 0));
-            if (main_mode == Mode::F16 && bound >= 2048) {
-                if (collect(q, 2048, list)) return 1;
-                std::vector<LaneItem> items;
-                std::vector<uint8_t> seen;
-                for (uint32_t slot : list) {                      // re-run the packed PAIR the slot belongs to
-                    const uint32_t g = slot / kGroupSeqs, l = (slot % kGroupSeqs) / 2;      // lane l holds the group's sequences 2l and 2l + 1
+        }
+        if (main_mode == Mode::F16 && ladder_rung(batch, 2048, Mode::PK16)) return 1;
+        if (ladder_rung(batch, 32767, Mode::I32)) return 1;
+    }
+    return 0;
+}
+
+// one rung for a batch of queries: scan (slots whose score reached `thr` are listed and zeroed), re-run in `mode`
+int SearchRun::ladder_rung(const std::vector<uint32_t> &batch, int thr, Mode mode)
+{
+    std::vector<uint32_t> qs;
+    for (uint32_t q : batch)
+        if ((long)qm[q] * c->max_pos >= thr) qs.push_back(q);
+    if (qs.empty()) return 0;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(S, 0xFFFFFFFEull);   // the shared list holds one score row's worth of slots
+    uint32_t *d_count = c->d_satlist.p + cap;
+    HIP_TRY(c->d_ladder_counts.reserve(qs.size()));
+    std::vector<std::vector<uint32_t>> slots(qs.size());     // per query: the slots that left the tier's range
+    for (int round = 0;; ++round) {                          // (again while the shared list overflows: what did not fit is still in the score rows)
+        HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream3));
+        for (size_t i = 0; i < qs.size(); ++i) {
+            HIP_TRY(launch_collect_saturated(c->d_scores.p + (size_t)qs[i] * S, S, thr, c->d_satlist.p, d_count, cap, c->stream3));
+            HIP_TRY(hipMemcpyAsync(c->d_ladder_counts.p + i, d_count, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream3));   // where query i's part of the list ends
+        }
+        std::vector<uint32_t> counts(qs.size());
+        HIP_TRY(hipMemcpyAsync(counts.data(), c->d_ladder_counts.p, qs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream3));
+        HIP_TRY(hipStreamSynchronize(c->stream3));
+        const bool overflow = counts.back() > cap;
+        if (overflow && round > 1000) return fail("promotion ladder: the list of alignments that left the %s range does not drain", thr == 2048 ? "f16" : "int16");
+        const uint32_t total = std::min(counts.back(), cap);
+        if (total) {
+            std::vector<uint32_t> list(total);
+            HIP_TRY(hipMemcpyAsync(list.data(), c->d_satlist.p, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream3));
+            HIP_TRY(hipStreamSynchronize(c->stream3));
+            for (size_t i = 0; i < qs.size(); ++i) {
+                const uint32_t l0 = std::min(i ? counts[i - 1] : 0u, cap), l1 = std::min(counts[i], cap);
+                slots[i].insert(slots[i].end(), list.begin() + l0, list.begin() + l1);
+            }
+        }
+        if (!overflow) break;
+    }
+    {
+        // every query's re-run items: its own part of one list, longest first, boundary columns counted from the part's start
+        std::vector<LaneItem> items;
+        std::vector<LaneQuery> lqs;
+        uint64_t bnd_cols = 0, pass_total = 0;
+        size_t multi = 0;
+        std::vector<uint8_t> seen;
+        for (size_t i = 0; i < qs.size(); ++i) {
+            const uint32_t q = qs[i];
+            const std::vector<uint32_t> &list = slots[i];
+            const uint32_t l0 = 0, l1 = (uint32_t)list.size();
+            const size_t first = items.size();
+            if (mode == Mode::PK16) {
+                seen.assign(seen.size(), 0);
+                for (uint32_t k = l0; k < l1; ++k) {                    // re-run the packed PAIR the slot belongs to
+                    const uint32_t slot = list[k], g = slot / kGroupSeqs, l = (slot % kGroupSeqs) / 2;      // lane l holds the group's sequences 2l and 2l + 1
                     const uint32_t pair = g * 64 + l;
                     if (seen.size() <= pair) seen.resize(pair + 1, 0);
                     if (seen[pair]) continue;
@@ -1229,22 +1254,55 @@ int SearchRun::promotion_ladder()
                     li.slot_a = gd.seq0 + 2 * l; li.slot_b = gd.seq0 + 2 * l + 1;
                     if (li.ncols) items.push_back(li);
                 }
-                c->promoted16 += list.size();
-                if (rerun(q, Mode::PK16, items)) return 1;
+                c->promoted16 += l1 - l0;
+            } else {
+                for (uint32_t k = l0; k < l1; ++k) {
+                    const uint32_t slot = list[k], g = slot / kGroupSeqs, within = slot % kGroupSeqs;
+                    LaneItem li{};
+                    li.db = c->groups[g].db; li.lane = within / 2; li.half = within % 2;
+                    li.ncols = (c->seq_len[slot] + kChunkCols - 1) / kChunkCols * kChunkCols;
+                    li.slot_a = slot; li.slot_b = 0;
+                    if (li.ncols) items.push_back(li);
+                }
+                c->promoted += items.size() - first;
             }
-            if (bound < 32767) continue;                         // cannot saturate int16
-            if (collect(q, 32767, list)) return 1;
-            std::vector<LaneItem> items;
-            for (uint32_t slot : list) {
-                const uint32_t g = slot / kGroupSeqs, within = slot % kGroupSeqs;
-                LaneItem li{};
-                li.db = c->groups[g].db; li.lane = within / 2; li.half = within % 2;
-                li.ncols = (c->seq_len[slot] + kChunkCols - 1) / kChunkCols * kChunkCols;
-                li.slot_a = slot; li.slot_b = 0;
-                if (li.ncols) items.push_back(li);
+            if (items.size() == first) continue;
+            std::stable_sort(items.begin() + first, items.end(), [](const LaneItem &a, const LaneItem &b) { return a.ncols > b.ncols; });
+            uint64_t cols = 0;
+            for (size_t k = first; k < items.size(); ++k) {
+                if (cols + items[k].ncols > 0xFFFFFFFFull) return fail("promotion re-runs of query %u exceed 2^32 boundary columns", q);
+                items[k].bnd_off = (uint32_t)cols; cols += items[k].ncols;
             }
-            c->promoted += items.size();
-            if (rerun(q, Mode::I32, items)) return 1;
+            LaneQuery lq{qm[q], qps[q].prof_off, qps[q].mpad, (uint64_t)q * S};
+            lq.items0 = (uint32_t)first; lq.n_items = (uint32_t)(items.size() - first); lq.cols = cols;
+            lqs.push_back(lq);
+            const uint64_t rp = (qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows);
+            pass_total += rp;
+            if (rp > 1) { bnd_cols += cols + 64; ++multi; }
+        }
+        if (!items.empty()) {
+            size_t prog_need = 0;
+            for (const LaneQuery &lq : lqs) prog_need += (size_t)((lq.m + 64 * kLaneRows - 1) / (64 * kLaneRows)) * lq.n_items;
+            LaneScratch &sc = c->rerun_scratch;
+            if (items.size() > c->d_rerun_items.cap || bnd_cols > sc.bnd[0].cap || (multi && prog_need > sc.prog.cap) || pass_total > sc.queue.cap || lqs.size() > sc.lq.cap) {
+                // growing a buffer frees the old one, which waits for the whole device: rare (first big batch)
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(c->d_rerun_items.reserve(items.size() * 2));
+                HIP_TRY(sc.queue.reserve(std::max<size_t>(256, pass_total * 2)));
+                if (bnd_cols) { HIP_TRY(sc.bnd[0].reserve(bnd_cols * 2)); HIP_TRY(sc.bnd[1].reserve(bnd_cols * 2)); }
+                HIP_TRY(sc.prog.reserve(std::max<size_t>(1, prog_need * 2)));
+                HIP_TRY(sc.lq.reserve(lqs.size() * 2 + 8));
+                HIP_TRY(sc.block_map.reserve((size_t)c->num_cu * 6 + 4096 + 2 * pass_total));
+            }
+            HIP_TRY(hipMemcpyAsync(c->d_rerun_items.p, items.data(), items.size() * sizeof(LaneItem), hipMemcpyHostToDevice, c->stream3));
+            HIP_TRY(hipStreamSynchronize(c->stream3));       // `items` is a host temporary; stream 3 has drained: the previous rung's tables are free
+            sc.lq_used = sc.bm_used = 0;
+            LaneList ll;
+            ll.items.p = c->d_rerun_items.p; ll.items.cap = c->d_rerun_items.cap;
+            ll.n = 0; ll.cols = 0; ll.cell_cols = 0;
+            const int rc = run_lane_batch(c, mode, kLaneRows, lqs, ll, c->stream3, sc);
+            ll.items.p = nullptr; ll.items.cap = 0;           // borrowed
+            if (rc) return rc;
         }
     }
     return 0;

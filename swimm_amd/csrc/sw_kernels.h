@@ -97,12 +97,12 @@ struct LaneQ {
     uint32_t m;                 // query rows
     uint32_t passes;            // ceil(m / (64 * rows per lane)); all passes run in ONE launch, chained per item
     uint32_t queue0;            // queue[queue0 + pass]: work cursor of (query, pass), zeroed before the launch
-    uint32_t prog0;             // prog[(prog0 + pass) * n_items + item]: boundary columns published so far (global column + 1), zeroed
+    uint32_t prog0;             // prog[prog0 + pass * n_items + item]: boundary columns published so far (global column + 1), zeroed
+    uint32_t items0, n_items;   // the query's items: items[items0 .. items0 + n_items) (the tail: every query the whole list; re-runs: each its own)
     uint32_t pad_;
 };
 struct LaneParams {
-    const LaneItem *items;      // the same list for every query of the launch
-    uint32_t n_items;
+    const LaneItem *items;
     const LaneQ *lq;
     const uint32_t *block_map;  // [grid]: query << 8 | pass of every workgroup, ascending in pass (a producer is dispatched before its consumers)
     uint32_t *queue;

@@ -765,10 +765,11 @@ size_t lane_lds_bytes(int rows_per_lane) { return round16((size_t)kCodes * prof_
 // what lane 0 feeds into the pipeline for one chunk of 4 columns (wave-uniform)
 struct LaneFeed {
     uint32_t wa, wb;        // residues of the 4 columns (sequence A / B)
-    uint2 b[kChunkCols];    // top boundary (H, F) of the 4 columns, zero in the first pass
+    uint2 b[kChunkCols];    // top boundary (H, F) of the 4 columns, zero in the first pass (the chunk being computed: scalar registers)
+    uint2 bv;               // ... as it is loaded: lane jj (0..3) holds column jj -- one register pair for the chunk in flight, not four
     uint32_t item, col0;    // item index, first column's index in the boundary buffer
     uint32_t half;          // int32 mode: which of wa / wb is the sequence
-    uint32_t flags[kChunkCols];
+    uint32_t fbits;         // 1 = a real chunk of an item (not pipeline fill / drain), 2 = its first column starts the item, 4 = its last column ends it
 };
 
 // Passes of a long query (512 rows each) are CHAINED inside one launch: the workgroups of pass p take the
@@ -814,8 +815,10 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     const uint32_t rows = lq.m - r0 < (uint32_t)RP ? lq.m - r0 : (uint32_t)RP;
     const bool first_pass = pass == 0, last_pass = pass + 1 == lq.passes;
     uint32_t *const queue = p.queue + lq.queue0 + pass;
-    const uint32_t *const prog_in = p.prog + (size_t)(lq.prog0 + (first_pass ? 0 : pass - 1)) * p.n_items;   // only read when pass > 0
-    uint32_t *const prog_out = p.prog + (size_t)(lq.prog0 + pass) * p.n_items;
+    const LaneItem *const items = p.items + lq.items0;
+    const uint32_t n_items = lq.n_items;
+    const uint32_t *const prog_in = p.prog + lq.prog0 + (size_t)(first_pass ? 0 : pass - 1) * n_items;   // only read when pass > 0
+    uint32_t *const prog_out = p.prog + lq.prog0 + (size_t)pass * n_items;
     const unsigned long long *const bnd_in = p.bnd[(pass + 1) & 1] + lq.bnd0;
     unsigned long long *const bnd_out = p.bnd[pass & 1] + lq.bnd0;
     int32_t *const out = p.out + lq.out_off;
@@ -863,16 +866,15 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             uint32_t idx = 0;
             if (lane == 0) idx = atomicAdd(queue, 1u);
             idx = __builtin_amdgcn_readfirstlane(idx);
-            if (idx >= p.n_items) {
+            if (idx >= n_items) {
                 feeding = false;
             } else {
-                const LaneItem iv = p.items[idx];
+                const LaneItem iv = items[idx];
                 it_idx = idx; cc = 0; nch = iv.ncols / C; it_db = iv.db; it_lane = iv.lane; it_half = iv.half; it_bnd = iv.bnd_off;
                 seen = 0;
             }
         }
-#pragma unroll
-        for (int jj = 0; jj < C; ++jj) { f.b[jj] = make_uint2(0u, 0u); f.flags[jj] = 0; }
+        f.bv = make_uint2(0u, 0u); f.fbits = 0;
         f.wa = f.wb = 0x18181818u;   // pad residues (code 24) while draining
         f.item = it_idx; f.col0 = 0; f.half = it_half;
         if (feeding) {
@@ -901,16 +903,12 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
                     if (p.agent_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
-#pragma unroll
-                for (int jj = 0; jj < C; ++jj) {
-                    const unsigned long long v = __hip_atomic_load(bnd_in + (size_t)f.col0 + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    f.b[jj] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+                {   // lane jj fetches column jj (the lanes above repeat the last column: same cache line, nothing extra)
+                    const unsigned long long v = __hip_atomic_load(bnd_in + (size_t)f.col0 + (lane < C ? lane : C - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    f.bv = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
                 }
             }
-#pragma unroll
-            for (int jj = 0; jj < C; ++jj) f.flags[jj] = kFlagReal;
-            if (cc == 0) f.flags[0] |= kFlagStart;
-            if (cc + 1 == nch) f.flags[C - 1] |= kFlagEnd;
+            f.fbits = 1u | (cc == 0 ? 2u : 0u) | (cc + 1 == nch ? 4u : 0u);
             ++cc;
             return true;
         }
@@ -941,20 +939,22 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
         // vector registers), so that only the chunk in flight costs VGPRs
         LaneFeed cur;
         cur.wa = __builtin_amdgcn_readfirstlane(nxt.wa); cur.wb = __builtin_amdgcn_readfirstlane(nxt.wb);
+        cur.fbits = __builtin_amdgcn_readfirstlane(nxt.fbits);
+        uint32_t cflags[C];
 #pragma unroll
         for (int jj = 0; jj < C; ++jj) {
-            cur.b[jj].x = __builtin_amdgcn_readfirstlane(nxt.b[jj].x); cur.b[jj].y = __builtin_amdgcn_readfirstlane(nxt.b[jj].y);
-            cur.flags[jj] = __builtin_amdgcn_readfirstlane(nxt.flags[jj]);
+            cur.b[jj].x = __builtin_amdgcn_readlane(nxt.bv.x, jj); cur.b[jj].y = __builtin_amdgcn_readlane(nxt.bv.y, jj);
+            cflags[jj] = (cur.fbits & 1u ? kFlagReal : 0u) | (jj == 0 && (cur.fbits & 2u) ? kFlagStart : 0u) | (jj == C - 1 && (cur.fbits & 4u) ? kFlagEnd : 0u);
         }
         cur.item = __builtin_amdgcn_readfirstlane(nxt.item); cur.col0 = __builtin_amdgcn_readfirstlane(nxt.col0);
         cur.half = __builtin_amdgcn_readfirstlane(nxt.half);
         if (!last_pass) publish();   // the previous chunk's boundary stores have retired (the feed loads were waited for just above)
         more = produce(nxt);         // loads of the next chunk are in flight while this one is computed
         if (!PK && cur.half) cur.wa = cur.wb;
-        hist_real = (hist_real << 1) | ((cur.flags[0] & kFlagReal) ? 1u : 0u);
+        hist_real = (hist_real << 1) | (cur.fbits & 1u);
 #pragma unroll
         for (int jj = 0; jj < C; ++jj) {
-            uint32_t d0 = ((cur.wa >> (8 * jj)) & 0xffu) | cur.flags[jj];
+            uint32_t d0 = ((cur.wa >> (8 * jj)) & 0xffu) | cflags[jj];
             if (PK) d0 |= ((cur.wb >> (8 * jj)) & 0xffu) << 8;
             // residue stream, one step ahead: fetch the scores of the NEXT column now
             const uint32_t Dn = dpp_shr1(oDn, d0);
@@ -993,7 +993,7 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             if (!last_pass && mine)   // one lane, four stores per real chunk (lane 63's chunks are chunk aligned)
                 __hip_atomic_store(bnd_out + Cin, ((unsigned long long)oF << 32) | oH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine && (D & kFlagEnd)) {   // every pass contributes the best of its own rows
-                const LaneItem *iv = p.items + Sin;
+                const LaneItem *iv = items + Sin;
                 if (M == 2) {
                     const v2h b2 = __builtin_bit_cast(v2h, oT);
                     atomicMax(out + iv->slot_a, (int)(float)b2.x);

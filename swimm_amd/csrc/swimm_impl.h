@@ -115,7 +115,11 @@ struct LaneScratch {
 };
 
 // one query of a lane-systolic launch, as the host hands it over
-struct LaneQuery { uint32_t m; uint64_t prof_off; uint32_t prof_stride; uint64_t out_off; };
+struct LaneQuery {
+    uint32_t m; uint64_t prof_off; uint32_t prof_stride; uint64_t out_off;
+    uint32_t items0 = 0, n_items = 0;   // its own part of the item list (promotion re-runs); n_items == 0: the whole list (the tail)
+    uint64_t cols = 0;                  // ... and that part's boundary columns
+};
 
 struct Uploader;      // the thread that copies a lazily uploaded database (below, with upload_chunk)
 
@@ -257,6 +261,7 @@ struct swimm_hip_ctx {
     LaneScratch rerun_scratch;          // lane kernel on stream 3 (promotion re-runs)
     DevBuf<LaneItem> d_rerun_items;
     DevBuf<uint32_t> d_satlist;
+    DevBuf<uint32_t> d_ladder_counts;   // promotion ladder: where every query's part of the shared list ends
     // stats of the last search
     double kernel_ms = 0;
     uint64_t cells = 0, promoted = 0, promoted16 = 0;

@@ -136,6 +136,8 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    touches; no launch boundary).  -1 = default: formed when the call has two or more
  *                    queries (or streams its database in) and the database is small beside the chip; 0 = never: one launch
  *                    per pass of every query ("split", "bnd_mib" apply); 1 = always, every query joins
+ *   "bulk_streams"   0 = default (two): the streams the passes of consecutive multi-pass queries take turns on; 1..4 = that many
+ *                    (three and four measured slower: the further streams share hardware queues with the ones in use)
  *   "cut"            35 = default: per device group, the longest pairs leave the group (they run whole through the lane-systolic kernel
  *                    beside the pipeline kernel, which then stops at the longest pair left) when that saves more padded pipeline
  *                    cells than value/10 times the pairs' own cells; 0 = never

@@ -323,6 +323,7 @@ struct SearchRun {
     // the launch plan
     Mode main_mode = Mode::F16;
     bool lane_room = false, many_short = false, alternate = false;
+    int bulk_k = 2;                         // streams the multi-pass queries' launches take turns on (alternate)
     bool tall = false;                      // the batch is ONE group-resident launch of tall workgroups beside the tail kernels (plan_queries)
     uint32_t longest_cols = 0;
     std::vector<QueryPlan> qps;
@@ -775,6 +776,20 @@ int SearchRun::plan_queries()
     uint32_t n_multi = 0;
     for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && !in_batch[q] && qps[q].passes > 1;
     alternate = n_multi >= 2 && c->opt_alternate && !streaming;
+    // ... and on more than two when every launch is bound by its longest group's chain (a database that is small beside the
+    // chip: c3 at a tenth of its size, 423 groups for 256 workgroups, makespan 4x the mean load): the launches of up to four
+    // queries side by side fill the CUs that the one before leaves idle while its last chains run out.
+    bulk_k = 2;
+    if (alternate) {
+        int per_cu = 1;
+        if (wgs_per_cu(c, main_mode, qps[qn - 1].T, qps[qn - 1].W, false, &per_cu)) return 1;
+        const double imb = plan_imbalance(c, n_workgroups(c, per_cu));
+        // (measured, profiles/r03_c3_scales.txt: three and four streams LOSE -- c3 at 10 % 5 880 -> 4 830 / 5 490 GCUPS, at 30 % 7 560 -> 7 190 /
+        // 7 360 -- the further streams share hardware queues with the ones in use; the option stays for A/B runs)
+        bulk_k = c->opt_bulk_streams > 0 ? c->opt_bulk_streams : 2;
+        bulk_k = (int)std::min<uint32_t>((uint32_t)bulk_k, n_multi);
+        if (dbg) fprintf(stderr, "swimm_hip: makespan / mean load of the bulk groups %.2f: the queries' passes take turns on %d streams\n", imb, bulk_k);
+    }
     c->batch_now = any_batch;
     return 0;
 }
@@ -884,7 +899,13 @@ int SearchRun::size_buffers()
         if (dbg) fprintf(stderr, "swimm_hip: buffer sizes known %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
         HIP_TRY(c->d_bnd.reserve(need_bnd));
         if (alternate || c->batch_now || streaming) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
-        if (c->batch_now && streaming) HIP_TRY(c->d_bnd_c.reserve(need_bnd));
+        if ((c->batch_now && streaming) || (alternate && bulk_k > 2)) HIP_TRY(c->d_bnd_c.reserve(need_bnd));
+        if (alternate && bulk_k > 3) HIP_TRY(c->d_bnd_d.reserve(need_bnd));
+        for (int i = 0; i < 2 && alternate && i + 2 < bulk_k; ++i)
+            if (!c->stream_t[i]) {
+                HIP_TRY(hipStreamCreate(&c->stream_t[i]));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_tail_t[i], hipEventDisableTiming));
+            }
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
@@ -902,10 +923,6 @@ int SearchRun::size_buffers()
             if (tail_items > 0 && reserve_lane_scratch(c, c->tail_scratch, tail_cols, tail_items, passes_of[0], queries_of[0], multi, ranges.size())) return 1;
             for (int i = 0; i < 2; ++i) {
                 if (tail_items == 0 || queries_of[i + 1] == 0) continue;
-                if (!c->stream_t[i]) {
-                    HIP_TRY(hipStreamCreate(&c->stream_t[i]));
-                    HIP_TRY(hipEventCreateWithFlags(&c->ev_tail_t[i], hipEventDisableTiming));
-                }
                 if (reserve_lane_scratch(c, c->tail_scratch_t[i], tail_cols, tail_items, passes_of[i + 1], queries_of[i + 1], 0, ranges.size())) return 1;
             }
             if (dbg && tail_items) fprintf(stderr, "swimm_hip: tail of %zu items: %zu / %zu / %zu queries with 8 / 4 / 2 rows per lane, %zu chained passes in all\n", tail_items, queries_of[0], queries_of[1], queries_of[2], passes_of[0]);
@@ -928,7 +945,7 @@ int SearchRun::issue()
     for (int i = 0; i < 2; ++i) if (c->stream_t[i]) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], c->ev_ready, 0));
     HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_ready, 0));
     uint32_t one_pass_seen = 0;
-    double alt_rows[2] = {0, 0};
+    double alt_rows[4] = {0, 0, 0, 0};
     HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
     while (c->ev_query.size() < 2 * (size_t)qn) {
         hipEvent_t e;
@@ -1009,7 +1026,9 @@ int SearchRun::issue()
             }
             for (int ci = 0; ci < 3; ++ci) {
                 if (cls[ci].empty()) continue;
-                hipStream_t st = ci == 0 ? c->stream2 : c->stream_t[ci - 1];
+                // (one stream for all classes, the long queries' launch -- the longest chains -- first: a stream of its own per class
+                // measured 2-3 % slower on c3 at 30 % and 100 % of its size; HIP multiplexes streams onto four hardware queues)
+                hipStream_t st = c->stream2;
                 LaneScratch &sc = ci == 0 ? c->tail_scratch : c->tail_scratch_t[ci - 1];
                 if (run_lane_batch(c, main_mode == Mode::F16 ? Mode::F16 : Mode::PK16, ci == 0 ? kLaneRows : ci == 1 ? 4 : 2, cls[ci], *ll, st, sc)) return 1;
                 if (dbg) fprintf(stderr, "swimm_hip: range %zu: tail of %u items for %zu queries in one launch (%d rows per lane)\n", ri, ll->n, cls[ci].size(), ci == 0 ? kLaneRows : ci == 1 ? 4 : 2);
@@ -1053,9 +1072,12 @@ int SearchRun::issue()
             // Each query goes to the stream with less work so far (padded rows), longest first: strict turns left one stream
             // 6 % more rows on c3 and the other idle for the last 60 ms.
             if (alternate && !rotated[q] && !qps[q].resident && !(many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows)) {
-                const int pick = alt_rows[1] < alt_rows[0];
+                int pick = 0;
+                for (int k = 1; k < bulk_k; ++k) if (alt_rows[k] < alt_rows[pick]) pick = k;
                 alt_rows[pick] += (double)qps[q].passes * qps[q].W * qps[q].T;
-                if (pick) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
+                if (pick == 1) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
+                else if (pick == 2) { bulk_stream = c->stream_t[0]; bnd = &c->d_bnd_c; }
+                else if (pick == 3) { bulk_stream = c->stream_t[1]; bnd = &c->d_bnd_d; }
             }
             if (streaming && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
             if (dbg)

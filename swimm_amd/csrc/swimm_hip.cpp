@@ -97,7 +97,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     swimm_hip_clear_db(c);
     pool_trim(c);
     for (hipEvent_t e : c->part_ev) (void)hipEventDestroy(e);
-    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_qdesc.release(); c->d_wave_out.release();
+    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_bnd_d.release(); c->d_qdesc.release(); c->d_wave_out.release();
     if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = c->pin_used = 0; }
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_t[0].release(); c->tail_scratch_t[1].release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release(); c->d_ladder_counts.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -483,6 +483,9 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "rotate")) {
         c->opt_rotate = value != 0;
+    } else if (!strcmp(key, "bulk_streams")) {
+        if (value < 0 || value > 4) return fail("bulk_streams must be 0 (auto) .. 4");
+        c->opt_bulk_streams = value;
     } else if (!strcmp(key, "cut")) {
         if (value < 0 || value > 1000) return fail("cut must be 0 (never) .. 1000 (tenths: cost of a lane-systolic cell against a padded pipeline cell)");
         c->opt_cut = value;

@@ -243,6 +243,8 @@ struct swimm_hip_ctx {
     DevBuf<int16_t> d_prof;
     DevBuf<uint2> d_bnd, d_bnd_b;       // pass-boundary rows; the second one for the queries whose passes run on stream_b
     DevBuf<uint2> d_bnd_c;              // ... and a third for the group-resident launches of a database that streams in (three ranges in flight)
+    DevBuf<uint2> d_bnd_d;              // ... and a fourth: chain-bound searches run the passes of up to four queries side by side
+    int opt_bulk_streams = 0;           // streams the passes of consecutive multi-pass queries take turns on: 0 = by the work lists' imbalance (2..4), else 1..4
     Uploader *up = nullptr;             // the thread that copies a lazily uploaded database (created with the first recorded chunk)
     void *pin = nullptr;                // pinned arena the work lists travel through (list_copy)
     size_t pin_cap = 0, pin_used = 0;

@@ -136,6 +136,13 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    touches; no launch boundary).  -1 = default: formed when the call has two or more
  *                    queries (or streams its database in) and the database is small beside the chip; 0 = never: one launch
  *                    per pass of every query ("split", "bnd_mib" apply); 1 = always, every query joins
+ *   "batch_order"    0 = default: a group-resident batch hands its (group, query) items out group by group; 1 = a batch of one-pass queries
+ *                    query by query (a workgroup keeps its strip of the profile from item to item).  Measured equal (300 queries of
+ *                    80-120 residues x 1.0e8 residues: 7 245 against 7 270 GCUPS): the per-item profile switch is not what a batch of
+ *                    one-pass queries loses against per-pass launches on a large database
+ *   "sp_threshold"   65536 = default (none): queries of at least this many rows are aligned by the SCORE-PROFILE kernel instead of the
+ *                    query-profile pipeline (the reference's query_length_threshold: `-p S` = 0, `-p Q` = none, `-p A -u N` = N,
+ *                    MICsearch.c:39-43, swimm.c:81-85).  Exact like every path; slower on gfx950 at every query length
  *   "bulk_streams"   0 = default (two): the streams the passes of consecutive multi-pass queries take turns on; 1..4 = that many
  *                    (three and four measured slower: the further streams share hardware queues with the ones in use)
  *   "cut"            35 = default: per device group, the longest pairs leave the group (they run whole through the lane-systolic kernel

@@ -100,6 +100,13 @@ static void shard_slabs(slab_t *v, uint32_t n, int gpus)
 
 typedef struct { double kernel_ms, seconds; uint64_t promoted; uint32_t chunk_count; } leg_stats;
 
+/* -p / -u (swimm.c:81-85, MICsearch.c:39-43): queries of at least `threshold` rows are aligned with the SCORE profile, shorter
+ * ones with the QUERY profile.  -p Q: no query; -p S: every query; -p A (the default): the reference takes the score profile
+ * from -u rows on because it wins there on its hardware; on gfx950 it is the slower technique at every query length (a
+ * workgroup has too few query rows in flight to amortise the table), so the adaptive choice resolves to
+ * the query profile for every query and -u only names where the switch WOULD be considered. */
+static int sp_threshold_of(const swimm_options *o) { return o->profile == 'S' ? 0 : 65536; }
+
 /* Host leg (mode 0, and the host's share in mode 2): `count` sequences starting at the short end of the sorted
  * database; per query the first `top` rows of the listing, indices = sorted-database indices.  The lane-interleaved
  * copy of the database is built by the caller beforehand (untimed, like swimm.c:46 before the search call). */
@@ -149,6 +156,7 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
         /* the preprocessed database stays in host memory for the whole run: slabs stream in while the search runs
          * (transfer overlapped with compute, MICsearch.c:85-91) */
         if (!bad && api->set_option(ctx, "lazy_upload", 1)) bad = 1;
+        if (!bad && api->set_option(ctx, "sp_threshold", sp_threshold_of(o))) bad = 1;
         if (!bad && api->set_queries(ctx, q->a, q->m, q->disp, (uint32_t)q->count, submat, o->open_gap, o->extend_gap)) bad = 1;
         for (uint32_t c = 0; !bad && c < n_slabs; ++c)
             if (slabs[c].owner == g && api->add_sequences(ctx, lengths + slabs[c].first, codes + slabs[c].offset, slabs[c].count,
@@ -281,6 +289,7 @@ static void *gpu_worker_main(void *p)
     int64_t *pi = (int64_t *)malloc(q->count * w->top * sizeof(int64_t));
     int bad = api->create(w->device, &ctx);
     if (!bad) bad = api->set_option(ctx, "lazy_upload", 1);     /* the slab streams in piece by piece while the search runs */
+    if (!bad) bad = api->set_option(ctx, "sp_threshold", sp_threshold_of(w->o));
     if (!bad) bad = api->set_queries(ctx, q->a, q->m, q->disp, (uint32_t)q->count, w->submat, w->o->open_gap, w->o->extend_gap);
     claim_t c;
     double rate = 0;
@@ -511,7 +520,9 @@ int main(int argc, char **argv)
             printf("Execution mode:\t\t\tConcurrent host CPU and MI355X (%d CPU threads and %d GPUs)\n", o.cpu_threads, o.num_gpus);
         else
             printf("Execution mode:\t\t\tMI355X only (%d GPUs)\n", o.num_gpus);
-        printf("Profile technique:\t\tQuery Profile in LDS\n");
+        if (o.profile == 'S') printf("Profile technique:\t\tScore Profile in LDS\n");
+        else if (o.profile == 'Q') printf("Profile technique:\t\tQuery Profile in LDS\n");
+        else printf("Profile technique:\t\tAdaptive Profile (threshold = %d; on gfx950 the query profile is the faster one at every length: Query Profile in LDS)\n", o.query_length_threshold);
         printf("Instruction set:\t\tgfx950 packed binary16 -> int16 -> int32 ladder (vector length = 128)\n");
         printf("Max. chunk size:\t\t%ld bytes\n", o.max_chunk_size);
         printf("Chunk count:\t\t\t%ld \n", (long)gst.chunk_count);

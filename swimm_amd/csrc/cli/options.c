@@ -29,8 +29,8 @@ static struct argp_option options[] = {
     {"cpu_threads", 'c', "<integer>", 0, "Number of host threads (default: 4).", 3},
     {"num_gpus", 'x', "<integer>", 0, "Number of MI355X GPUs. Valid option only when execution mode is 1 (default: 1).", 3},
     {"mic_threads", 't', "<integer>", 0, "Accepted for compatibility; ignored (the GPU schedules its own wavefronts).", 3},
-    {"mic_profile", 'p', "<char>", 0, "Accepted for compatibility ('Q', 'S' or 'A'); the GPU path always stages a query profile in LDS.", 3},
-    {"query_length_threshold", 'u', "<integer>", 0, "Accepted for compatibility; ignored.", 3},
+    {"mic_profile", 'p', "<char>", 0, "Profile technique on the GPU: 'Q' query profile, 'S' score profile, 'A' adaptive (default: resolves to the query profile, the faster one on gfx950 at every query length).", 3},
+    {"query_length_threshold", 'u', "<integer>", 0, "Query length from which the adaptive profile would consider the score profile (default: 567).", 3},
     {"vector_length", 'v', "<integer>", 0, "Vector length for execution mode 0: 16 or 32 (default: 16). The GPU path always uses 128 sequences per wavefront.", 3},
     {"top", 'r', "<integer>", 0, "Number of scores to show (default: 10).", 3},
     {"max_chunk_size", 'k', "<integer>", 0, "Maximum chunk size in bytes. Valid option only when execution mode is 1 (default: 100663296).", 3},

@@ -21,8 +21,8 @@ typedef struct {
     int cpu_threads;              /* -c 4 */
     int num_gpus;                 /* -x 1 (number of accelerators) */
     int accel_threads;            /* -t 240, accepted and ignored */
-    char profile;                 /* -p Q|S|A, accepted; the GPU path always uses a query profile */
-    int query_length_threshold;   /* -u 567, accepted and ignored */
+    char profile;                 /* -p Q|S|A: query profile, score profile (sw_sp_kernel), adaptive (resolves to Q on gfx950) */
+    int query_length_threshold;   /* -u 567: where the adaptive profile would consider the score profile */
     int vector_length;            /* -v 16|32 for -m 0; the GPU path lays the database out 128 wide */
     unsigned long top;            /* -r 10 */
     unsigned long max_chunk_size; /* -k 100663296 */

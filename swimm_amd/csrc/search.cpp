@@ -53,6 +53,9 @@ int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl
     p.queue = c->d_queue.p + c->queue_next++;
     p.qdesc = qd;
     p.n_queries = nq;
+    // (a batch of one-pass queries in query-major order: consecutive items of a workgroup are consecutive groups of one query, and
+    // its waves keep their strip of the profile from item to item; with multi-pass queries every item-pass switches the window anyway)
+    p.n_groups = (c->opt_batch_order && max_passes == 1 && nq > 1) ? pl.n_items : 0;
     p.wave_out = c->d_wave_out.p;
     p.bnd_wg_cols = pl.queue_cols[0];
     p.r0 = 0;
@@ -178,6 +181,32 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
             c->launches++;
             c->cells += seg_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * (mode == Mode::I32 ? 64 : 128);
         }
+    }
+    return 0;
+}
+
+// The score-profile path of a query (option "sp_threshold"): one launch per pass of 32 rows over every group of the range.
+int run_sp_passes(swimm_hip_ctx *c, const QueryPlan &qp, const Plan &pl, const int8_t *qcodes, int32_t *out_row, hipStream_t st, DevBuf<uint2> &bnd)
+{
+    if (qp.passes > 1 && bnd.cap < pl.bnd_cols * 64) return fail("internal: boundary buffer too small for the score-profile passes");
+    for (int pass = 0; pass < qp.passes; ++pass) {
+        if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
+        SpParams p{};
+        p.items = pl.queue_items.p;
+        p.n_items = pl.n_items;
+        p.queue = c->d_queue.p + c->queue_next++;
+        p.qcodes = qcodes;
+        p.r0 = (uint32_t)(pass * kSpRows);
+        p.sub16 = c->d_sub16.p;
+        p.bnd = bnd.p;
+        p.first_pass = pass == 0;
+        p.last_pass = pass == qp.passes - 1;
+        p.out = out_row;
+        p.goe = c->open_gap + c->extend_gap;
+        p.ge = c->extend_gap;
+        HIP_TRY(launch_sp((int)std::min<uint32_t>(pl.n_items, (uint32_t)c->num_cu * 6), p, st));
+        c->launches++;
+        c->cells += pl.total_chunks * kChunkCols * (uint64_t)kSpRows * 128;
     }
     return 0;
 }
@@ -323,6 +352,8 @@ struct SearchRun {
     // the launch plan
     Mode main_mode = Mode::F16;
     bool lane_room = false, many_short = false, alternate = false;
+    std::vector<uint8_t> use_sp;            // queries that run through the score-profile kernel (option "sp_threshold")
+    std::vector<size_t> qcode_off;          // ... and where their padded residue codes start in d_qcodes
     int bulk_k = 2;                         // streams the multi-pass queries' launches take turns on (alternate)
     bool tall = false;                      // the batch is ONE group-resident launch of tall workgroups beside the tail kernels (plan_queries)
     uint32_t longest_cols = 0;
@@ -391,12 +422,14 @@ int SearchRun::plan_for(size_t ri, int T, int W, bool resident, bool whole_db, D
     if (wgs_per_cu(c, main_mode, T, W, resident, &per_cu)) return 1;
     const int n_wg = n_workgroups(c, per_cu);
     if (!streaming) return get_db_plan(c, main_mode, n_wg, whole_db, out);
-    auto it = stream_plans[ri].find(n_wg);
+    const bool no_tail = resident || whole_db;         // (every group through the launch: no lane-systolic tail beside it)
+    const int key = n_wg * 2 + (no_tail ? 1 : 0);
+    auto it = stream_plans[ri].find(key);
     if (it == stream_plans[ri].end()) {
-        DbPlan &dp = stream_plans[ri][n_wg];
+        DbPlan &dp = stream_plans[ri][key];
         bool exact = true;
         for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[up_order[ci].chunk].lens_known;
-        if (make_db_plan(c, main_mode, n_wg, resident, ranges[ri], exact, dp)) return 1;
+        if (make_db_plan(c, main_mode, n_wg, no_tail, ranges[ri], exact, dp)) return 1;
         *out = &dp;
     } else {
         *out = &it->second;
@@ -406,7 +439,7 @@ int SearchRun::plan_for(size_t ri, int T, int W, bool resident, bool whole_db, D
 
 int SearchRun::plan_of(size_t ri, uint32_t q, DbPlan **out)
 {
-    return plan_for(ri, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, rotated[q] != 0 || (qps[q].resident && !tall), out);
+    return plan_for(ri, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, rotated[q] != 0 || use_sp[q] != 0 || (qps[q].resident && !tall), out);
 }
 
 // Which short queries share workgroups.  Candidates: the one-pass queries of up to 72 rows that run without a tail kernel
@@ -422,7 +455,7 @@ int SearchRun::build_stacks()
     for (int pass = 0; pass < 2; ++pass) {               // the batch's members, then the rotating ones
         std::map<int, std::vector<std::pair<int, uint32_t>>> cls;     // T -> (strips, query)
         for (uint32_t q = 0; q < qn; ++q) {
-            if (!(pass == 0 ? in_batch[q] != 0 : rotated[q] != 0) || qm[q] > 72) continue;
+            if (!(pass == 0 ? in_batch[q] != 0 : rotated[q] != 0) || qm[q] > 72 || use_sp[q]) continue;
             int bt = 0, bs = 0;
             double bc = 0;
             for (int s = 1; s <= 2; ++s)
@@ -618,6 +651,9 @@ int SearchRun::plan_queries()
     if (dbg) fprintf(stderr, "swimm_hip: ranges laid out, uploader started %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     qps.assign(qn, QueryPlan{});
     rotated.assign(qn, 0);
+    // the reference's adaptive profile (MICsearch.c:39-43): queries of at least query_length_threshold rows take the score profile
+    use_sp.assign(qn, 0);
+    for (uint32_t q = 0; q < qn; ++q) use_sp[q] = main_mode == Mode::F16 && c->opt_dynamic && (int)qm[q] >= c->opt_sp_threshold;
     uint32_t n_short = 0;
     for (uint32_t q = 0; q < qn; ++q) n_short += qm[q] <= 64 * kLaneRows;
     // (with a handful of short queries the last ones' chains would stick out at the end of the search; and a database
@@ -653,7 +689,7 @@ int SearchRun::plan_queries()
             int per_cu = 1;
             if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, true, &per_cu)) return 1;
             const double per_wg = (double)c->groups.size() / (qps[q].passes == 1 ? n_workgroups(c, per_cu) : multi_wg);
-            in_batch[q] = !pick || per_wg < (qps[q].passes == 1 ? 2.0 : 6.0);
+            in_batch[q] = !use_sp[q] && (!pick || per_wg < (qps[q].passes == 1 ? 2.0 : 6.0));
             joined += in_batch[q];
         }
         // A batch launch is one persistent kernel for the whole batch: lane-systolic tail kernels launched beside it would
@@ -691,7 +727,7 @@ int SearchRun::plan_queries()
     c->batch_now = false;
     if (rotate || batch_formed)
         for (uint32_t q = 0; q < qn; ++q)
-            if (!in_batch[q] && qm[q] <= 64 * kLaneRows) {
+            if (!in_batch[q] && !use_sp[q] && qm[q] <= 64 * kLaneRows) {
                 rotated[q] = choose_plan(c, main_mode, qm[q], false, true, &qps[q]) == 0;   // fails when no one-pass shape exists
                 if (!rotated[q] && batch_formed) { in_batch[q] = 1; if (choose_batch_shapes(c, main_mode, qm + q, 1, one_plan)) return 1; qps[q] = one_plan[0]; }   // ... then it stays in the batch
             }
@@ -727,7 +763,7 @@ int SearchRun::plan_queries()
         if (dbg) fprintf(stderr, "swimm_hip: launches per pass estimated at %.1f ms, one launch of 12 x 24-row workgroups at %.1f ms: %s\n", est_pp * 1e3, est_tall * 1e3, tall ? "tall batch" : "per pass");
         if (tall)
             for (uint32_t q = 0; q < qn; ++q) {
-                if (rotated[q] || stack_of[q] >= 0) continue;
+                if (rotated[q] || stack_of[q] >= 0 || use_sp[q]) continue;
                 in_batch[q] = 1;
                 qps[q].T = T; qps[q].W = W;
                 qps[q].passes = (int)((qm[q] + T * W - 1) / (T * W));
@@ -746,6 +782,9 @@ int SearchRun::plan_queries()
             const Stack &st = stacks[stack_of[q]];
             qps[q].T = st.T; qps[q].W = st.W; qps[q].passes = 1; qps[q].mpad = 0;
         }
+        if (use_sp[q]) {                                   // the score-profile kernel: one wave of 32 rows per workgroup
+            qps[q].T = kSpRows; qps[q].W = 1; qps[q].passes = (int)((qm[q] + kSpRows - 1) / kSpRows); qps[q].mpad = 0; qps[q].sp = true;
+        } else
         if (!in_batch[q] && !rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;   // (a batch's shapes are chosen above)
         if (dbg)
             fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
@@ -774,7 +813,7 @@ int SearchRun::plan_queries()
     // of its own), so that the end of every launch -- the last workgroups finishing alone -- is covered by a kernel of
     // the other query.  (Within ONE such query the even/odd split of run_passes does the same.)
     uint32_t n_multi = 0;
-    for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && !in_batch[q] && qps[q].passes > 1;
+    for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && !in_batch[q] && !use_sp[q] && qps[q].passes > 1;
     alternate = n_multi >= 2 && c->opt_alternate && !streaming;
     // ... and on more than two when every launch is bound by its longest group's chain (a database that is small beside the
     // chip: c3 at a tenth of its size, 423 groups for 256 workgroups, makespan 4x the mean load): the launches of up to four
@@ -821,6 +860,30 @@ int SearchRun::upload_profiles()
             rv[q].mpad = qps[q].mpad; rv[q].prof_off = qps[q].prof_off;      // one profile per query, padded for the tallest plan
             rv[q].mode = main_mode; rv[q].dynamic = qps[q].dynamic; rv[q].resident = false;
         }
+    {   // the score-profile kernel's inputs: its queries' residue codes (padded with the dummy residue) and the matrix as binary16
+        std::vector<int8_t> codes;
+        qcode_off.assign(qn, 0);
+        for (uint32_t q = 0; q < qn; ++q) {
+            if (!use_sp[q]) continue;
+            qcode_off[q] = codes.size();
+            const int8_t *qa = c->qcodes.data() + qdisp[q];
+            codes.insert(codes.end(), qa, qa + qm[q]);
+            codes.resize((codes.size() + kSpRows - 1) / kSpRows * kSpRows, (int8_t)23);
+        }
+        if (!codes.empty()) {
+            uint16_t sub16[kCodes * kSpSubStride] = {};      // [database residue d][query residue q]; d = 24 (lane padding) scores 0
+            for (int d = 0; d < 24; ++d)
+                for (int qr = 0; qr < 24; ++qr) {
+                    const _Float16 h = (_Float16)(float)c->submat[qr * 32 + d];
+                    memcpy(&sub16[d * kSpSubStride + qr], &h, sizeof(uint16_t));
+                }
+            HIP_TRY(c->d_qcodes.reserve(codes.size()));
+            HIP_TRY(c->d_sub16.reserve(kCodes * kSpSubStride));
+            HIP_TRY(hipMemcpyAsync(c->d_qcodes.p, codes.data(), codes.size(), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_sub16.p, sub16, sizeof sub16, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));          // (host temporaries)
+        }
+    }
     if (dbg) fprintf(stderr, "swimm_hip: launch shapes chosen and profiles built %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     HIP_TRY(c->d_prof.reserve(prof_elems));
     HIP_TRY(hipMemcpyAsync(c->d_prof.p, prof.data(), prof_elems * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
@@ -896,6 +959,12 @@ int SearchRun::size_buffers()
                 tail_cols = std::max<size_t>(tail_cols, dp->tail.cols);
                 tail_items = std::max<size_t>(tail_items, dp->tail.n);
             }
+        for (uint32_t q = 0; q < qn; ++q) {                 // the score-profile queries: a launch per pass of 32 rows and range, the boundary of a whole range
+            if (!use_sp[q]) continue;
+            launch_total += ranges.size() * (size_t)qps[q].passes;
+            if (qps[q].passes > 1)
+                for (const Range &rg : ranges) need_bnd = std::max<uint64_t>(need_bnd, rg.cols * 64);
+        }
         if (dbg) fprintf(stderr, "swimm_hip: buffer sizes known %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
         HIP_TRY(c->d_bnd.reserve(need_bnd));
         if (alternate || c->batch_now || streaming) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
@@ -1014,7 +1083,7 @@ int SearchRun::issue()
             const LaneList *ll = nullptr;
             for (uint32_t k = 0; k < qn; ++k) {
                 const uint32_t q = qn - 1 - k;
-                if (stack_of[q] >= 0 || (qps[q].resident && !tall) || rotated[q]) continue;      // (every group through the pipeline kernel)
+                if (stack_of[q] >= 0 || (qps[q].resident && !tall) || rotated[q] || use_sp[q]) continue;      // (every group through the pipeline kernel)
                 DbPlan *dp = nullptr;
                 if (plan_of(ri, q, &dp)) return 1;
                 if (dp->tail.n == 0) continue;
@@ -1043,6 +1112,12 @@ int SearchRun::issue()
             DbPlan *dp = nullptr;
             if (plan_of(ri, q, &dp)) return 1;
             int32_t *row = c->d_scores.p + (size_t)q * S;
+            if (use_sp[q]) {                               // the score-profile kernel takes every group of the range, pass by pass
+                if (dp->have_main && run_sp_passes(c, qps[q], dp->main, c->d_qcodes.p + qcode_off[q], row, c->stream, c->d_bnd)) return 1;
+                HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
+                HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], c->stream));
+                continue;
+            }
             if (dbg)
                 fprintf(stderr, "swimm_hip: range %zu query %u: %d workgroups, %u tail items, main %s\n", ri, q, dp->main.n_wg, dp->tail.n, dp->have_main ? "yes" : "no");
             // The long-sequence tail (a few long serial chains, one wave each) runs beside the bulk kernel: 3 bulk waves

@@ -61,6 +61,8 @@ struct PipeParams {
     uint32_t n_queries;         // (qdesc != nullptr selects the group-resident kernel: every workgroup takes a group through all
                                 // the passes of an item's query back to back)
     uint32_t bnd_wg_cols;       // group-resident launches: bnd holds this many columns per workgroup, touched by it alone
+    uint32_t n_groups;          // group-resident launches, query-major item order (> 0): item id = query rank * n_groups + group rank -- a workgroup
+                                // takes consecutive groups of ONE query, so its profile strip stays staged from item to item; 0 = group-major
     const uint32_t *wave_out;   // stacks of short queries: per (stack, wave) the score row of the wave's member (group-resident launches: indexed
                                 // through QDesc::wave_tab; a per-pass launch: non-null selects the stack below)
     uint32_t seam_mask;         // per-pass launch of ONE stack: its seam bits ...
@@ -117,6 +119,25 @@ struct LaneParams {
 size_t lane_lds_bytes(int rows_per_lane);
 // rows_per_lane: kLaneRows (any query), or 4 / 2 for a one-pass launch of a query of <= 256 / <= 128 rows
 hipError_t launch_lane(Mode mode, int rows_per_lane, int n_wg, const LaneParams &p, hipStream_t s);
+
+// ---- score-profile kernel (the reference's second lookup technique, MICsearch.c:257-313: per block of database columns a table
+// [query residue][column][lane] built once and read linearly by every query row).  One wave per workgroup, 32 query rows per pass,
+// the table of a chunk of 4 columns in LDS (24 KB); selected per query by the option "sp_threshold" (`swimm -p S`, `-p A -u`).
+constexpr int kSpRows = 32;
+constexpr int kSpSubStride = 40;  // halfs per database residue in the kernel's matrix copy: 24 query residues + padding (80 B: 16-byte reads, banks spread)
+struct SpParams {
+    const Item *items;          // every group of the range, longest first
+    uint32_t n_items;
+    uint32_t *queue;            // work cursor, zeroed before the launch
+    const int8_t *qcodes;       // the query's residue codes, padded with the dummy code 23 to a multiple of kSpRows
+    uint32_t r0;                // first query row of this pass
+    const uint16_t *sub16;      // substitution matrix as binary16 bits, transposed: [25 database residues][kSpSubStride], entry q = S(query residue q, d)
+    uint2 *bnd;                 // pass boundary rows (H, F per column and lane), as in PipeParams
+    int first_pass, last_pass;
+    int32_t *out;               // the query's score row
+    int goe, ge;
+};
+hipError_t launch_sp(int n_wg, const SpParams &p, hipStream_t s);
 
 size_t pipe_lds_bytes(int rows_per_wave, int waves, bool resident);
 // which (tier, rows per wave, hand-over scheme) kernels exist

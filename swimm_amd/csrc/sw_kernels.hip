@@ -219,7 +219,7 @@ __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *q) { return
                         next_it = it + 1 < it_end ? it + 1 : kNoItem; \
                     } \
                     if (next_it != kNoItem) { \
-                        const Item niv = load_item(p.items, RES ? next_it / nq : next_it); \
+                        const Item niv = load_item(p.items, RES ? (qmajor ? next_it % p.n_groups : next_it / nq) : next_it); \
                         ndb = niv.db; ncc = 0; nhalf = niv.half; \
                     } else { \
                         have_next = false; \
@@ -376,6 +376,7 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
         pf_win = win;
     };
     const uint32_t nq = RES ? p.n_queries : 1u;
+    const bool qmajor = RES && p.n_groups != 0;
     uint64_t bnd_off = 0;
     const uint8_t *dbp = nullptr;
     uint32_t nwa = 0, nwb = 0;     // residues of the wave's next chunk, loaded one step ahead
@@ -405,13 +406,13 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
             if (cc == 0) {                        // first chunk of a new item (RES: item-pass): reset the DP state
                 // the item is the same for the whole wave: one scalar load, descriptor in scalar registers
                 const uint32_t vi = __builtin_amdgcn_readfirstlane(it);
-                const uint32_t gi = RES ? vi / nq : vi;
+                const uint32_t gi = RES ? (qmajor ? vi % p.n_groups : vi / nq) : vi;
                 const Item iv = load_item(p.items, gi);
                 nch = iv.ncols / C; dbp = iv.db; seq0 = iv.seq0;
                 half = iv.half;
                 bnd_off = RES ? (uint64_t)blockIdx.x * p.bnd_wg_cols : iv.bnd_off;
                 if (RES && pass == 0) {               // a new (group, query) item: the query's parameters, one scalar load
-                    cur_q = nq - 1 - (vi - gi * nq);
+                    cur_q = nq - 1 - (qmajor ? vi / p.n_groups : vi - gi * nq);
                     const QDesc qd = load_qdesc(p.qdesc, cur_q);
                     passes = qd.passes; q_prof = p.prof + qd.prof_off; q_stride = qd.prof_stride; q_out = p.out + qd.out_off;
                     seam = false;
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
                 } else {
                     const uint32_t nv = DYN ? __builtin_amdgcn_readfirstlane(seq[(n + 1) & (kSeqRing - 1)]) : (it + 1 < it_end ? it + 1 : kNoItem);
                     if (nv != kNoItem) {
-                        const uint32_t ng = nv / nq, nqi = nq - 1 - (nv - ng * nq);
+                        const uint32_t nqi = nq - 1 - (qmajor ? nv / p.n_groups : nv - (nv / nq) * nq);
                         const int nwin = (int)(nqi << 16);
                         if (nwin != staged_win) {
                             const QDesc nqd = load_qdesc(p.qdesc, nqi);
@@ -740,6 +741,92 @@ const char *pipe_kernel_symbol(Mode mode, int T, bool dynamic, bool resident)
 {
     const void *f = resident ? kernel_ptr_t<true, true>(mode, T) : dynamic ? kernel_ptr_t<true, false>(mode, T) : kernel_ptr_t<false, false>(mode, T);
     return f ? hipKernelNameRefByPtr(f, nullptr) : nullptr;
+}
+
+// ---- score-profile kernel ------------------------------------------------------------------------
+// The reference's second lookup technique (K7, MICsearch.c:257-313; `-p S`, and the long queries of `-p A -u N`, swimm.c:81-85):
+// instead of looking every substitution score up by (query row, database residue), a table sp[query residue q][column][lane] =
+// (S(q, residue of sequence A), S(q, residue of sequence B)) is built once per chunk of database columns, and every query row
+// reads ITS residue's line of it, lane-linear, no permute.  Here: one wave = one workgroup aligns a device group (128 sequences,
+// packed binary16 pairs) against kSpRows query rows per pass, the strip boundary between passes through HBM exactly as in the
+// pipeline kernel; the chunk's table is 24 x 4 x 64 dwords = 24 KB of LDS.  On gfx950 the technique cannot pay (DESIGN.md
+// section 6b.4: building the table costs ~96 instructions per column and workgroup, reading it saves one v_perm_b32 per row
+// pair, and a workgroup has too few rows in flight to amortise the difference); it exists because the reference's interface has
+// it, selected by the option "sp_threshold", and it is exact like every other path (tests/test_gpu_parity.py).
+__global__ void __launch_bounds__(64) sw_sp_kernel(const SpParams p)
+{
+    constexpr int T = kSpRows, C = kChunkCols;
+    __shared__ uint32_t sp[24 * C * 64];
+    __shared__ __attribute__((aligned(16))) uint16_t sub[kCodes * kSpSubStride];     // [database residue][query residue]: a residue's 24 scores are three 16-byte reads
+    const int lane = threadIdx.x;
+    for (int i = lane; i < kCodes * kSpSubStride / 2; i += 64) ((uint32_t *)sub)[i] = ((const uint32_t *)p.sub16)[i];
+    uint32_t qoff[T];                     // the pass's query rows: where each row's residue starts in the table (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < T; ++r) qoff[r] = __builtin_amdgcn_readfirstlane((uint32_t)(uint8_t)p.qcodes[p.r0 + r]) * (uint32_t)(C * 64);
+    __syncthreads();
+    const v2h ngoe = OpsF16::splat(-p.goe), nge = OpsF16::splat(-p.ge);
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(p.queue, 1u);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= p.n_items) break;
+        const Item iv = load_item(p.items, it);
+        const uint32_t nch = iv.ncols / C;
+        v2h H[T], E[T];
+#pragma unroll
+        for (int r = 0; r < T; ++r) { H[r] = OpsF16::zero(); E[r] = OpsF16::zero(); }
+        v2h best = OpsF16::zero(), diag_top = OpsF16::zero();
+        for (uint32_t cc = 0; cc < nch; ++cc) {
+            const unsigned long long w = *(const __attribute__((address_space(1))) unsigned long long *)(uintptr_t)(iv.db + ((size_t)cc * 64 + lane) * 8);
+            const uint32_t wa = (uint32_t)w, wb = (uint32_t)(w >> 32);
+            uint2 bin[C];
+#pragma unroll
+            for (int jj = 0; jj < C; ++jj) bin[jj] = p.first_pass ? make_uint2(0u, 0u) : p.bnd[(iv.bnd_off + (uint64_t)cc * C + jj) * 64 + lane];
+            // the chunk's score profile: for each of the 24 query residues the pair of scores against this lane's two residues
+            // (a residue's 24 scores: three ds_read_b128 per sequence; the pairs are formed two query residues at a time)
+#pragma unroll
+            for (int jj = 0; jj < C; ++jj) {
+                const uint32_t da = (wa >> (8 * jj)) & 0xffu, db = (wb >> (8 * jj)) & 0xffu;
+                const uint4 *ra = (const uint4 *)(sub + da * kSpSubStride), *rb = (const uint4 *)(sub + db * kSpSubStride);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint4 a = ra[k], b = rb[k];
+                    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int q = (k * 4 + w) * 2;
+                        sp[(q * C + jj) * 64 + lane] = __builtin_amdgcn_perm(bw[w], aw[w], 0x05040100u);
+                        sp[((q + 1) * C + jj) * 64 + lane] = __builtin_amdgcn_perm(bw[w], aw[w], 0x07060302u);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int jj = 0; jj < C; ++jj) {
+                v2h hd = diag_top;
+                diag_top = OpsF16::from_bits(bin[jj].x);
+                v2h F = OpsF16::from_bits(bin[jj].y);
+#pragma unroll
+                for (int r = 0; r < T; r += 2)
+                    cell2<OpsF16>(hd, H[r], E[r], H[r + 1], E[r + 1], F, best, OpsF16::from_bits(sp[qoff[r] + jj * 64 + lane]),
+                                  OpsF16::from_bits(sp[qoff[r + 1] + jj * 64 + lane]), ngoe, nge);
+                if (!p.last_pass) p.bnd[(iv.bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = make_uint2(OpsF16::bits(H[T - 1]), OpsF16::bits(F));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_wave_barrier();          // (the next chunk's table overwrites this one)
+        }
+        const v2h b2 = best;
+        atomicMax(p.out + iv.seq0 + 2 * lane, (int)(float)b2.x);
+        atomicMax(p.out + iv.seq0 + 2 * lane + 1, (int)(float)b2.y);
+    }
+}
+
+hipError_t launch_sp(int n_wg, const SpParams &p, hipStream_t s)
+{
+    if (n_wg < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sw_sp_kernel, dim3(n_wg), dim3(64), 0, s, p);
+    return hipGetLastError();
 }
 
 // ---- lane-systolic kernel ------------------------------------------------------------------------

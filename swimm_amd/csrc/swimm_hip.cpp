@@ -97,7 +97,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     swimm_hip_clear_db(c);
     pool_trim(c);
     for (hipEvent_t e : c->part_ev) (void)hipEventDestroy(e);
-    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_bnd_d.release(); c->d_qdesc.release(); c->d_wave_out.release();
+    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_bnd_d.release(); c->d_qcodes.release(); c->d_sub16.release(); c->d_qdesc.release(); c->d_wave_out.release();
     if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = c->pin_used = 0; }
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_t[0].release(); c->tail_scratch_t[1].release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release(); c->d_ladder_counts.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -443,6 +443,7 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *c, uint32_t q, char *buf, size_t b
     if (!c || !buf || buf_len == 0) return fail("swimm_hip_last_kernel_name: NULL argument");
     if (q >= c->last_plans.size()) return fail("swimm_hip_last_kernel_name: query %u was not part of the last search", q);
     const QueryPlan &qp = c->last_plans[q];
+    if (qp.sp) { snprintf(buf, buf_len, "swimm::sw_sp_kernel(swimm::SpParams)"); return 0; }
     const char *sym = pipe_kernel_symbol(qp.mode, qp.T, qp.dynamic, qp.resident);
     if (!sym) return fail("swimm_hip_last_kernel_name: no kernel for rows_per_wave=%d", qp.T);
     int status = 0;
@@ -483,6 +484,11 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "rotate")) {
         c->opt_rotate = value != 0;
+    } else if (!strcmp(key, "batch_order")) {
+        c->opt_batch_order = value != 0;
+    } else if (!strcmp(key, "sp_threshold")) {
+        if (value < 0 || value > 65536) return fail("sp_threshold must be 0 (every query through the score-profile kernel) .. 65536 (none)");
+        c->opt_sp_threshold = value;
     } else if (!strcmp(key, "bulk_streams")) {
         if (value < 0 || value > 4) return fail("bulk_streams must be 0 (auto) .. 4");
         c->opt_bulk_streams = value;

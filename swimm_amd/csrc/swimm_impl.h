@@ -154,6 +154,7 @@ struct UploadPart { size_t chunk = 0; uint32_t g0 = 0, g1 = 0; hipEvent_t ready 
 struct QueryPlan {
     int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true, resident = false;
     double est_s = 0;                   // choose_plan: the predicted time of the query's launches (makespan of the work lists included)
+    bool sp = false;                    // the query runs through the score-profile kernel (option "sp_threshold")
     bool stack = false;                 // the "query" is a stack of short queries sharing one workgroup (QDesc in sw_kernels.h) ...
     uint32_t seam_mask = 0, wave_tab = 0;   // ... with these seams and this first entry in d_wave_out
 };
@@ -205,6 +206,10 @@ struct swimm_hip_ctx {
     int opt_cut = 35;                   // outlier pairs: a group's longest pairs leave it for the lane-systolic kernel when that saves the pipeline kernel more padded cells than opt_cut/10 x the pairs' own (0 = never)
     std::vector<uint32_t> cut_cols;     // per group: the columns the pipeline kernel aligns (<= ncols; the pairs that are longer are lane-systolic items as well)
     std::vector<uint8_t> cut_lane;      // per group: the first lane (pair) that is an outlier (64 = none)
+    int opt_sp_threshold = 65536;       // queries of at least this many rows use the score-profile kernel (the reference's query_length_threshold, MICsearch.c:39-43); 65536 = none
+    DevBuf<int8_t> d_qcodes;            // score-profile kernel: the residue codes of its queries, each padded with the dummy code to a multiple of 32
+    DevBuf<uint16_t> d_sub16;           // ... and the substitution matrix as binary16 bits [24][32]
+    int opt_batch_order = 0;            // group-resident batches of one-pass queries: 1 = query-major item order (a workgroup stays with a query), 0 = group-major (default; measured equal)
     int opt_stack = 1;                  // 1: short one-pass queries of a batch share workgroups (several queries stacked along the strips)
     int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
     std::vector<hipEvent_t> launch_ev;  // pairs (before, after), grown on demand
@@ -410,6 +415,7 @@ uint64_t resident_bnd_elems(const Plan &pl);
 int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl, const QDesc *qd, uint32_t nq, uint64_t pass_sum, uint32_t max_passes,
                        hipStream_t st, DevBuf<uint2> &bnd);
 int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl, int32_t *out_row, hipStream_t st, bool allow_split, DevBuf<uint2> &bnd);
+int run_sp_passes(swimm_hip_ctx *c, const QueryPlan &qp, const Plan &pl, const int8_t *qcodes, int32_t *out_row, hipStream_t st, DevBuf<uint2> &bnd);
 int lane_rows_for(const swimm_hip_ctx *c, uint32_t m);
 int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::vector<LaneQuery> &qs, const LaneList &ll, hipStream_t st, LaneScratch &sc);
 int reserve_lane_scratch(swimm_hip_ctx *c, LaneScratch &sc, size_t list_cols, size_t items, size_t pass_total, size_t queries, size_t multi_pass_queries, size_t launches = 1);

@@ -154,15 +154,19 @@ def test_search_over_several_devices(dbprefix, golden, mode):
 
 
 @pytest.mark.gpu
-def test_profile_flags_accepted_same_listing(dbprefix, golden):
-    """-p Q|S|A and -u (arguments.c:109-121, swimm.c:81-85): the flags of the reference's profile choice are part of
-    the command line; on the GPU there is one lookup scheme (DESIGN.md section 6b.4 says why the score profile cannot
-    win there), so every setting must give the reference listing"""
+def test_profile_flags_select_the_lookup_technique(dbprefix, golden):
+    """-p Q|S|A and -u (arguments.c:109-121, swimm.c:81-85): `-p S` aligns every query with the SCORE-profile kernel (the table
+    [query residue][column][lane] of MICsearch.c:257-313, built per chunk in LDS), `-p Q` with the query profile, `-p A` -- the
+    default -- resolves to the query profile on gfx950.  Every setting must give the reference listing."""
     q = os.path.join(GOLDEN, golden["query_fasta"])
-    for flags in (("-p", "S", "-u", "100"), ("-p", "Q"), ("-p", "A"), ("-p", "A", "-u", "0"), ("-u", "65535")):
+    for flags, technique in ((("-p", "S", "-u", "100"), "Score Profile in LDS"), (("-p", "S"), "Score Profile in LDS"), (("-p", "Q"), "Query Profile in LDS"),
+                             (("-p", "A"), "Adaptive Profile (threshold = 567;"), (("-p", "A", "-u", "0"), "Adaptive Profile (threshold = 0;"),
+                             (("-u", "65535"), "Adaptive Profile (threshold = 65535;")):
         p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-r", "40", *flags)
         check_listing(p.stdout, golden, dbprefix, "blosum62_g10_e2", 40)
-        assert "Profile technique:\t\tQuery Profile in LDS" in p.stdout
+        assert "Profile technique:\t\t" + technique in p.stdout, p.stdout[-700:]
+    p = run("-S", "search", "-q", q, "-d", dbprefix, "-m", "2", "-c", "2", "-r", "413", "-p", "S")       # the hybrid queue's GPU workers too
+    check_listing(p.stdout, golden, dbprefix, "blosum62_g10_e2", 413)
     assert run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-p", "X", check=False).returncode == 1
     assert run("-S", "search", "-q", q, "-d", dbprefix, "-m", "1", "-u", "70000", check=False).returncode == 1
 

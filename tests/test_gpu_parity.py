@@ -292,3 +292,48 @@ def test_two_contexts_interleaved_on_one_thread(tmp_path, golden, monkeypatch):
             assert np.array_equal(ts[k], os_) and np.array_equal(ti[k], oi), k
     finally:
         A.close(); B.close()
+
+
+@pytest.mark.parametrize("threshold", [0, 200, 1000])
+def test_score_profile_kernel(searcher, gin, golden, threshold):
+    """The reference's second lookup technique (MICsearch.c:257-313, selected by query_length_threshold, MICsearch.c:39-43): queries of
+    at least `threshold` rows through the score-profile kernel, the others through the query-profile pipeline -- all golden cases
+    (multi-pass 3200-row query, both promotion rungs), resident and streamed in, and a seeded database with gaps and odd lengths."""
+    q, pp, chunked = gin
+    N = golden["search"]["n_sequences"]
+    try:
+        searcher.set_option("sp_threshold", threshold)
+        for name, c in golden["search"]["cases"].items():
+            sc = _run(searcher, q, chunked, 128, matrix(c["matrix"]), c["open"], c["extend"])
+            assert np.array_equal(sc[:, :N], load_npy(f"scores_{name}.npy")), name
+            if threshold == 0:
+                assert searcher.last_kernel_name(len(q["m"]) - 1) == "swimm::sw_sp_kernel(swimm::SpParams)"
+        searcher.clear_db()
+        searcher.set_option("lazy_upload", 1)
+        searcher.set_option("upload_piece_kib", 16)
+        searcher.set_queries(q["a"], q["m"], q["disp"], matrix("blosum62"), 10, 2)
+        vc = load_chunks(searcher, chunked, 128)
+        sc, _ = searcher.search(vc * 128)
+        assert np.array_equal(sc[:, :N], load_npy("scores_blosum62_g10_e2.npy"))
+        rng = np.random.default_rng(77 + threshold)
+        lens = np.sort(rng.integers(0, 700, 3000)).astype(np.uint16)
+        codes = rng.integers(0, 24, int(lens.astype(np.int64).sum())).astype(np.int8)
+        qs = [rng.integers(0, 24, int(n)).astype(np.int8) for n in (1, 31, 32, 33, 64, 333, 1001)]
+        m = np.array([len(x) for x in qs], np.uint16)
+        disp = np.concatenate([[0], np.cumsum(m.astype(np.int64))]).astype(np.uint32)
+        offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+        qs[5][:300] = codes[offs[2500]:offs[2500] + 300]
+        a = np.concatenate(qs)
+        searcher.clear_db()
+        searcher.set_option("lazy_upload", 0)
+        searcher.set_queries(a, m, disp, matrix("pam250"), 7, 1)
+        searcher.add_sequences(lens, codes, 0)
+        got, _ = searcher.search(3072)
+        one = port.assemble_single_chunk(lens.astype(np.int64), codes, 128, 5)
+        want = port.search_exact(a, m, disp, one["b"], one["n"], one["disp"], matrix("pam250"), 7, 1, 128)
+        assert np.array_equal(got[:, :3000], want[:, :3000])
+    finally:
+        searcher.set_option("sp_threshold", 65536)
+        searcher.set_option("lazy_upload", 0)
+        searcher.set_option("upload_piece_kib", 98304)
+        searcher.clear_db()

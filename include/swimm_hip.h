@@ -188,9 +188,10 @@ int swimm_hip_set_option(swimm_hip_ctx *ctx, const char *key, int value);
 /* Whole-call drop-in with the argument list of mic_search_knc_ap_multiple_chunks
  * (MICsearch.h:35-38, called at swimm.c:88-90): shards the chunks statically over `num_gpus`
  * devices (one host thread each), searches, scatters into `scores`
- * (stride vect_sequences_db_count * vl) and writes *workTime.  `mic_threads` and
- * `query_length_threshold` of the original are meaningless on a GPU and dropped; `vl` (the
- * lane width the chunks were assembled with) is added.  Returns 0 or an error status. */
+ * (stride vect_sequences_db_count * vl) and writes *workTime.  `mic_threads` of the original is
+ * meaningless on a GPU and dropped; `query_length_threshold` is the option "sp_threshold" (through
+ * SWIMM_HIP_OPTIONS for this call; default: no query takes the score profile); `vl` (the lane
+ * width the chunks were assembled with) is added.  Returns 0 or an error status. */
 int swimm_hip_search_chunks(const char *query_sequences, const uint16_t *query_sequences_lengths,
                             uint32_t query_sequences_count, const uint32_t *query_disp,
                             uint64_t vect_sequences_db_count, char **chunk_b, uint32_t chunk_count,

@@ -400,6 +400,9 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
             pending_valid = false;
         }
         bool pull = false;
+        // (the step's prologue -- item bookkeeping, boundary and ring reads -- runs at the priority the last column left, 0.  Raising it to 3
+        // here was measured in round 3, A/B in one process: no effect on any shape -- c2 27.17 vs 27.11 ms, the group-resident kernel with
+        // 8-wave workgroups 7 590 vs 7 574 GCUPS)
         const int c = s - k;                      // chunk index of this wave in the workgroup's sequence
         STAMP(tA);
         if (c >= 0 && it != kNoItem) {            // wave-uniform

@@ -601,6 +601,16 @@ def main():
                 r2["workload"] = name
                 secondary.append(r2)
             extra["secondary"] = secondary
+            c5 = secondary[1]
+            # the N = 1 point of north_star's strong-scaling series (GCUPS and HBM fraction at 1, 2, 4, 8 GPUs): the c5 record above, at a
+            # quarter of the database so that the line stays within minutes (`--workload c5 --scale 1` runs the whole database on one GPU)
+            extra["strong_scaling"] = {
+                "workload": c5["config"]["workload"], "scale": DEFAULT_SCALE["c5"] * args.secondary_scale, "value": c5["value"], "unit": "GCUPS", "n_gpus": 1,
+                "steps": c5["steps"], "warmup": c5["warmup"], "ms_per_step": c5["ms_per_step"],
+                "per_rank_kernel_gcups": [c5["valu_roofline"]["kernel_only_gcups"]],
+                "hbm_frac": c5["roofline"]["frac"] if c5["roofline"] else None,
+                "rccl_ranks": 0, "topr_exchange": "none", "bit_exact": c5["bit_exact_vs_reference"] and c5["merged_top20_matches_full_vectors"],
+                "note": "N = 1 at a quarter of the database (at N > 1 the whole 7e9-residue database is sharded: --strong-scale 1); GCUPS does not depend on the scale from 10 % up (profiles/r03_bench_c5_full.json: the whole database on one GPU)"}
         else:
             r2, ok2 = run_workload(env, args, "c5", args.strong_scale, args.secondary_steps, 1, 6.0, False, False)
             all_ok = all_ok and ok2

@@ -373,7 +373,7 @@ struct SearchRun {
     std::map<std::pair<int, int>, std::vector<Unit>> by_shape;
     std::vector<std::vector<QueryPlan>> rqps;                // streaming, per-pass launches: a launch shape per (range, query)
     size_t prof_elems = 0;
-    int tail_lanes = 1;                     // tail launches in flight at a time (decided with the buffer sizes)
+    int tail_lanes = 1;                     // lane-systolic tail launches per range: one per rows-per-lane class in use (informational)
     double stream_free[3] = {0, 0, 0};      // streaming, group-resident ranges: when each of the three streams is expected to have drained (s after t_begin)
 
     SearchRun(swimm_hip_ctx *ctx, uint32_t b, uint32_t e) : c(ctx), qb(b), qe(e) {}

@@ -230,6 +230,10 @@ def setup(args) -> Env:
         prop = torch.cuda.get_device_properties(env.dev_index)
         ident = (socket.gethostname(), str(getattr(prop, "uuid", "")), getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1),
                  getattr(prop, "pci_domain_id", -1))
+        if visible >= env.world and not env.share:
+            # every rank sees all the node's devices and took the one of its local rank: distinct by index, whatever the runtime
+            # reports as identity (a build that leaves uuid / PCI ids empty must not turn a real multi-GPU run into an error)
+            ident = ident + ("index", env.dev_index)
         idents = [None] * env.world
         dist.all_gather_object(idents, ident)
         env.physical_gpus = len(set(idents))

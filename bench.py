@@ -245,10 +245,10 @@ def setup(args) -> Env:
         if not env.share:
             err = None
             try:
-                # (a rank whose RCCL set-up fails leaves the others inside this collective: they give up after a minute and
+                # (a rank whose RCCL set-up fails leaves the others inside this collective: they give up after three minutes and
                 # everybody meets again in the gloo exchange below)
                 os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
-                env.rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=60))
+                env.rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
                 t = torch.ones(1, device="cuda")
                 dist.all_reduce(t, group=env.rccl)
                 torch.cuda.synchronize()

@@ -75,9 +75,9 @@ int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl
         HIP_TRY(hipMemcpyAsync(h, c->d_stamps.p, sizeof h, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (int w = 0; w < W; ++w)
-            fprintf(stderr, "stamps (resident batch of %u) wave %2d: load/wait %8.0f  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active of %llu steps per wg)\n", nq,
-                    w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4],
-                    (double)h[w * 8 + 3] / h[w * 8 + 4], h[w * 8 + 4] / n_wg, h[w * 8 + 5] / n_wg);
+            fprintf(stderr, "stamps (resident batch of %u) wave %2d: load/wait %8.0f (item start %6.0f | residues, boundary, ring %6.0f | next-chunk request %6.0f)  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active steps per wg)\n", nq,
+                    w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 5] / h[w * 8 + 4], (double)h[w * 8 + 6] / h[w * 8 + 4], (double)h[w * 8 + 7] / h[w * 8 + 4],
+                    (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4], (double)h[w * 8 + 3] / h[w * 8 + 4], h[w * 8 + 4] / n_wg);
         fprintf(stderr, "stamps: workgroup run time mean %.1f us, longest %.1f us; first start to last end %.1f us (%llu workgroups)\n",
                 (double)h[15 * 8 + 0] / h[15 * 8 + 4] / 100.0, (double)h[15 * 8 + 1] / 100.0, (double)(h[15 * 8 + 3] - h[15 * 8 + 2]) / 100.0, h[15 * 8 + 4]);
     }
@@ -163,10 +163,9 @@ int run_passes(swimm_hip_ctx *c, Mode mode, const QueryPlan &qp, const Plan &pl,
                 HIP_TRY(hipMemcpyAsync(h, c->d_stamps.p, sizeof h, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 for (int w = 0; w < qp.W; ++w)
-                    fprintf(stderr, "stamps wave %2d: load/wait %8.0f  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active of %llu steps per wg)\n",
-                            w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4],
-                            (double)h[w * 8 + 3] / h[w * 8 + 4], h[w * 8 + 4] / pl.n_wg, h[w * 8 + 5] / pl.n_wg);
-                fprintf(stderr, "stamps: most steps of any workgroup %llu, longest workgroup %.0f cycles\n", h[6], (double)h[7]);
+                    fprintf(stderr, "stamps wave %2d: load/wait %8.0f (item start %6.0f | residues, boundary, ring %6.0f | next-chunk request %6.0f)  compute %8.0f  tail %8.0f  barrier %8.0f  cycles per active step (%llu active steps per wg)\n",
+                            w, (double)h[w * 8 + 0] / h[w * 8 + 4], (double)h[w * 8 + 5] / h[w * 8 + 4], (double)h[w * 8 + 6] / h[w * 8 + 4], (double)h[w * 8 + 7] / h[w * 8 + 4],
+                            (double)h[w * 8 + 1] / h[w * 8 + 4], (double)h[w * 8 + 2] / h[w * 8 + 4], (double)h[w * 8 + 3] / h[w * 8 + 4], h[w * 8 + 4] / pl.n_wg);
                 if (getenv("SWIMM_STAMPS_DUMP")) {
                     std::vector<unsigned long long> pw(3072);
                     HIP_TRY(hipMemcpy(pw.data(), c->d_stamps.p + 128, pw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

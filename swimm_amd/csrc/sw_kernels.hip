@@ -384,6 +384,7 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
 
 #ifdef SWIMM_STAMPS
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, sumA = 0, sumB = 0, sumC = 0, sumD = 0, nact = 0;
+    unsigned long long tA1 = 0, tA2 = 0, sumA1 = 0, sumA2 = 0, sumA3 = 0;      // the prologue in three parts: item start | residues, boundary, ring | next-chunk request
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int s = 0;; ++s) {
@@ -454,6 +455,7 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+            STAMP(tA1);
             if (!RES || cc < nch) {               // (RES: a short group idles here to the pipeline's depth between two passes)
             // database residues of this chunk: 4 columns of the lane's sequence(s).  They were requested one
             // step ago (below): right after the barrier every wave would otherwise stall on this global load
@@ -499,6 +501,7 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
                 for (int jj = 0; jj < C; ++jj) bin[jj] = src[jj * 64];
             }
             if (RES && k == W - 1 && !last_pass) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous step's boundary stores have retired
+            STAMP(tA2);
             // Request the next chunk of this wave's stream (same item, or the first chunk of the next item).  Which item follows?
             // static: the next of the range; dynamic: the id wave 0 published in seq[] (a chunk that finds none is the last of the
             // workgroup's sequence).  AFTER the boundary loads, so that waiting for those (older, and retired in order) leaves this
@@ -628,6 +631,7 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
 #ifdef SWIMM_STAMPS
             STAMP(tD);
             sumA += tB - tA; sumB += tC - tB; sumC += tD - tC; nact++;
+            if (tA2 >= tA1 && tA1 >= tA && tB >= tA2) { sumA1 += tA1 - tA; sumA2 += tA2 - tA1; sumA3 += tB - tA2; }
 #endif
         }
         if (DYN && k == 0 && pull) {             // one pull per item finished: the workgroup that finishes first gets the longest group left
@@ -643,8 +647,8 @@ __global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_
 #ifdef SWIMM_STAMPS
     if (p.stamps && lane == 0) {
         atomicAdd(p.stamps + k * 8 + 0, sumA); atomicAdd(p.stamps + k * 8 + 1, sumB); atomicAdd(p.stamps + k * 8 + 2, sumC);
-        atomicAdd(p.stamps + k * 8 + 3, sumD); atomicAdd(p.stamps + k * 8 + 4, nact); atomicAdd(p.stamps + k * 8 + 5, (unsigned long long)(total + W - 1));
-        atomicMax(p.stamps + k * 8 + 6, (unsigned long long)(total + W - 1)); atomicMax(p.stamps + k * 8 + 7, sumA + sumB + sumC + sumD);
+        atomicAdd(p.stamps + k * 8 + 3, sumD); atomicAdd(p.stamps + k * 8 + 4, nact);
+        atomicAdd(p.stamps + k * 8 + 5, sumA1); atomicAdd(p.stamps + k * 8 + 6, sumA2); atomicAdd(p.stamps + k * 8 + 7, sumA3);
         if (k == 0) {   // when do workgroups end?  (100 MHz wall clock, same on every CU)
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();
             atomicAdd(p.stamps + 15 * 8 + 0, t - t_begin); atomicMax(p.stamps + 15 * 8 + 1, t - t_begin);

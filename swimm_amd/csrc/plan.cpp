@@ -278,13 +278,17 @@ int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_
     int Wof[8] = {};
     bool ok[8] = {};
     auto rows_of = [](int m, int T, int W) { return (double)((m + T * W - 1) / (T * W)) * T * W; };
+    // the group-resident instantiations against the per-pass ones the rate table was measured with (profiles/
+    // r03_resident_vs_per_pass_by_shape.txt): 20, 24 and 28 rows per wave lose 5-8 %, the others 1-2 %
+    static const double kResidentFactor[8] = {1.0, 1.0, 0.99, 0.94, 0.95, 0.925, 0.985, 0.983};
+    auto rate_of = [&](int ti, int W) { return (double)kShapeGcups[ti][W - 1] * kResidentFactor[ti]; };
     for (int ti = 7; ti >= 0; --ti) {
         const int T = 8 + 4 * ti;
         if (c->opt_T && T != c->opt_T) continue;
         if (!pipe_has_variant(mode, T)) continue;
         Wof[ti] = c->opt_W > 0 ? std::min(c->opt_W, T >= 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
         ok[ti] = true;
-        for (uint32_t q = 0; q < qn; ++q) cost[ti] += rows_of(qm[q], T, Wof[ti]) / kShapeGcups[ti][Wof[ti] - 1];
+        for (uint32_t q = 0; q < qn; ++q) cost[ti] += rows_of(qm[q], T, Wof[ti]) / rate_of(ti, Wof[ti]);
     }
     int common = -1;
     for (int ti = 7; ti >= 0; --ti)
@@ -292,11 +296,11 @@ int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_
     if (common < 0) return fail("no group-resident kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W);
     for (uint32_t q = 0; q < qn; ++q) {
         int pick = common;
-        const double cc = rows_of(qm[q], 8 + 4 * common, Wof[common]) / kShapeGcups[common][Wof[common] - 1];
+        const double cc = rows_of(qm[q], 8 + 4 * common, Wof[common]) / rate_of(common, Wof[common]);
         double bc = cc;
         for (int ti = 7; ti >= 0; --ti) {
             if (!ok[ti]) continue;
-            const double x = rows_of(qm[q], 8 + 4 * ti, Wof[ti]) / kShapeGcups[ti][Wof[ti] - 1];
+            const double x = rows_of(qm[q], 8 + 4 * ti, Wof[ti]) / rate_of(ti, Wof[ti]);
             if (x < 0.88 * cc && x < bc) { bc = x; pick = ti; }
         }
         QueryPlan &qp = qps[q];

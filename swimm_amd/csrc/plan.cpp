@@ -216,7 +216,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
         const int T = 8 + 4 * ti;
         if (c->opt_T && T != c->opt_T) continue;
         if (!pipe_has_variant(mode, T)) continue;
-        int maxW = (T > 28 || (T == 28 && resident_for(c, 2))) ? 12 : 16;        // __launch_bounds__ of the instantiations (the group-resident 28-row kernel needs 137 VGPRs)
+        int maxW = T > 28 ? 12 : 16;        // __launch_bounds__ of the instantiations
         if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
         const int strips = std::max(1, (m + T - 1) / T);
         for (int W = 1; W <= maxW; ++W) {
@@ -279,14 +279,15 @@ int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_
     bool ok[8] = {};
     auto rows_of = [](int m, int T, int W) { return (double)((m + T * W - 1) / (T * W)) * T * W; };
     // the group-resident instantiations against the per-pass ones the rate table was measured with (profiles/
-    // r03_resident_vs_per_pass_by_shape.txt): 20, 24 and 28 rows per wave lose 5-8 %, the others 1-2 %
-    static const double kResidentFactor[8] = {1.0, 1.0, 0.99, 0.94, 0.95, 0.925, 0.985, 0.983};
+    // r03_resident_vs_per_pass_by_shape.txt): 1-2 % for every shape, once the 20-, 24- and 28-row ones no longer re-pack their E
+    // registers at every step (they lost 5-8 % until then; see the Makefile's -disable-promote-alloca-to-vector)
+    static const double kResidentFactor[8] = {1.0, 1.0, 0.993, 0.981, 0.991, 0.990, 0.984, 0.983};
     auto rate_of = [&](int ti, int W) { return (double)kShapeGcups[ti][W - 1] * kResidentFactor[ti]; };
     for (int ti = 7; ti >= 0; --ti) {
         const int T = 8 + 4 * ti;
         if (c->opt_T && T != c->opt_T) continue;
         if (!pipe_has_variant(mode, T)) continue;
-        Wof[ti] = c->opt_W > 0 ? std::min(c->opt_W, T >= 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
+        Wof[ti] = c->opt_W > 0 ? std::min(c->opt_W, T > 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
         ok[ti] = true;
         for (uint32_t q = 0; q < qn; ++q) cost[ti] += rows_of(qm[q], T, Wof[ti]) / rate_of(ti, Wof[ti]);
     }

@@ -684,11 +684,25 @@ int SearchRun::plan_queries()
             if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, true, &per_cu)) return 1;
             if (qps[q].passes > 1) multi_wg = std::max(multi_wg, n_workgroups(c, per_cu));
         }
+        // (round 3, profiles/r03_short_query_sets.txt: a query that would run ALONE in one pass of a 12- or 16-wave workgroup
+        // but takes several of the batch's 4-wave passes gains from the batch at every database size tried -- 100 queries of
+        // 280-320 residues: 8 040 vs 7 560 against 1.0e8 residues, 8 100 vs 7 700 against 6.0e8, 8 140 vs 7 730 against 1.2e9;
+        // of 400-440: 8 370 vs 8 010 and 8 350 vs 8 030 -- so when every multi-pass member of the batch is of that kind,
+        // they join whatever the size; with longer queries among them (450-560 at 6.0e8: 7 930 vs 8 160) the limit of 6 stays.
+        // One-pass queries are judged by groups per CU, whatever their shape's occupancy: 1 000 queries of 20-60 residues
+        // 7 670 in the batch at 5.2 groups per CU, but 7 600 vs 7 830 at 8.3 and 7 650 vs 8 070 at 12.2.)
+        bool all_medium = true;
+        for (uint32_t q = 0; q < qn && all_medium; ++q) {
+            if (qps[q].passes == 1 || use_sp[q]) continue;
+            QueryPlan alone{};
+            c->batch_now = false;
+            all_medium = choose_plan(c, main_mode, qm[q], false, true, &alone) == 0;     // (fails when no one-pass shape holds the query)
+            c->batch_now = true;
+        }
+        const double per_cu_groups = (double)c->groups.size() / std::max(1, c->num_cu);
         for (uint32_t q = 0; q < qn; ++q) {
-            int per_cu = 1;
-            if (wgs_per_cu(c, main_mode, qps[q].T, qps[q].W, true, &per_cu)) return 1;
-            const double per_wg = (double)c->groups.size() / (qps[q].passes == 1 ? n_workgroups(c, per_cu) : multi_wg);
-            in_batch[q] = !use_sp[q] && (!pick || per_wg < (qps[q].passes == 1 ? 2.0 : 6.0));
+            const double per_wg = (double)c->groups.size() / multi_wg;
+            in_batch[q] = !use_sp[q] && (!pick || (qps[q].passes == 1 ? per_cu_groups < 6.0 : all_medium || per_wg < 6.0));
             joined += in_batch[q];
         }
         // A batch launch is one persistent kernel for the whole batch: lane-systolic tail kernels launched beside it would

@@ -252,7 +252,7 @@ __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *q) { return
 //      pipeline (fewer chunks than waves) idles to the pipeline's depth between two of its passes: wave 0 must not
 //      start pass p+1 of a column before the last wave has finished pass p of it.
 template <int T, int M, bool DYN, bool RES>
-__global__ void __launch_bounds__((T > 28 || (RES && T == 28)) ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
+__global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
 {
     static_assert(T % 4 == 0 && T >= 8, "strips are multiples of 4 rows");
     constexpr int TP = strip_lds_rows(T);
@@ -706,7 +706,7 @@ static hipError_t launch_any(Mode mode, int T, int W, int n_wg, const PipeParams
 hipError_t launch_pipe(Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
     if (W < 1 || W > kMaxWaves || n_wg < 1 || !pipe_has_variant(mode, T)) return hipErrorInvalidValue;
-    if ((T > 28 || (T == 28 && p.qdesc != nullptr)) && W > 12) return hipErrorInvalidValue;    // __launch_bounds__ of those instantiations
+    if (T > 28 && W > 12) return hipErrorInvalidValue;    // __launch_bounds__ of those instantiations
     const bool dyn = p.queue != nullptr;
     if (p.qdesc != nullptr) return dyn && p.n_queries > 0 ? launch_any<true, true>(mode, T, W, n_wg, p, s) : hipErrorInvalidValue;
     return dyn ? launch_any<true, false>(mode, T, W, n_wg, p, s) : launch_any<false, false>(mode, T, W, n_wg, p, s);

@@ -525,6 +525,7 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         release_plans(c);
     } else if (!strcmp(key, "lazy_upload")) {
         c->opt_lazy_upload = value != 0;
+        if (c->opt_lazy_upload && ensure_uploader(c)) return 1;      // (the uploader thread starts -- and warms up -- now, not inside the first search)
     } else if (!strcmp(key, "upload_head")) {
         c->opt_upload_head = value != 0;
     } else if (!strcmp(key, "upload_piece_kib")) {

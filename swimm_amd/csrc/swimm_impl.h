@@ -314,6 +314,7 @@ struct Uploader {
     std::condition_variable cv;
     std::vector<UploadPart> order;  // the job: the parts in the order they travel
     bool have_job = false, busy = false, quit = false, stop = false;
+    bool warm = false;              // the thread has made its first HIP calls (they cost up to 5 ms: not inside a search)
     size_t issued = 0;              // the first `issued` chunks of `order` have their `ready` event recorded
     bool failed = false;
     std::string err;
@@ -328,7 +329,10 @@ struct Uploader {
     void run()
     {
         bool dev_ok = ctx_enter(c) == 0;
+        if (dev_ok) (void)hipStreamQuery(c->stream_up);      // (the runtime's per-thread set-up happens here, once)
         std::unique_lock<std::mutex> lk(mu);
+        warm = true;
+        cv.notify_all();
         for (;;) {
             cv.wait(lk, [&]() { return have_job || quit; });
             if (quit) return;
@@ -349,6 +353,11 @@ struct Uploader {
             busy = false;
             cv.notify_all();
         }
+    }
+    void wait_warm()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return warm; });
     }
     void post(const std::vector<UploadPart> &job)
     {

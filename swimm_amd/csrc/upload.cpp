@@ -140,7 +140,10 @@ int upload_chunk(swimm_hip_ctx *c, ChunkRec &r) { return upload_part(c, r, 0, r.
 
 int ensure_uploader(swimm_hip_ctx *c)
 {
-    if (!c->up) c->up = new Uploader(c);
+    if (!c->up) {
+        c->up = new Uploader(c);
+        c->up->wait_warm();          // (once per context, when lazy uploads are switched on or the first chunk is recorded)
+    }
     return 0;
 }
 

@@ -58,7 +58,7 @@ def test_golden_all_cases(searcher, gin, golden):
                                   # group-resident passes (one launch per multi-pass query), also with a deep pipeline: most groups
                                   # are then shorter than the pipeline and idle between their passes
                                   {"resident": 1}, {"resident": 1, "tail_mode": 2}, {"resident": 1, "tail_mode": 1},
-                                  {"resident": 1, "tail_mode": 2, "rows_per_wave": 8, "waves": 16}, {"resident": 1, "tail_mode": 2, "rows_per_wave": 28, "waves": 8},
+                                  {"resident": 1, "tail_mode": 2, "rows_per_wave": 8, "waves": 16}, {"resident": 1, "tail_mode": 2, "rows_per_wave": 28, "waves": 8}, {"resident": 1, "tail_mode": 2, "rows_per_wave": 28, "waves": 16},
                                   {"resident": 1, "tail_mode": 2, "rows_per_wave": 36, "waves": 12}, {"resident": 1, "f16": 0, "tail_mode": 2, "rows_per_wave": 16, "waves": 5},
                                   {"resident": 1, "force_i32": 1, "rows_per_wave": 16, "waves": 3}, {"lane_room": 0}, {"lane_room": 1, "resident": 1}])
 def test_golden_kernel_variants(gin, golden, opts):

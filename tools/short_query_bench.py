@@ -16,7 +16,9 @@ total = int(L.astype(np.int64).sum())
 codes = host.recode(synth.residues(2, 7, 0, total))
 rng = np.random.default_rng(1)
 SETS = ((100, 600, 700), (60, 1200, 1400), (200, 50, 1500)) if os.environ.get('SQ_MEDIUM') else ((300, 80, 120), (100, 280, 320), (1000, 20, 60), (100, 600, 700), (60, 1200, 1400), (200, 50, 1500), (3, 80, 120), (1, 80, 120))
-if os.environ.get('SQ_ONLY'):
+if os.environ.get('SQ_SET'):            # e.g. SQ_SET=100,400,440: 100 queries of 400-440 residues
+    SETS = (tuple(int(x) for x in os.environ['SQ_SET'].split(',')),)
+elif os.environ.get('SQ_ONLY'):
     SETS = tuple(SETS[int(i)] for i in os.environ['SQ_ONLY'].split(','))
 for (nq, lo, hi) in SETS:
     ms = np.sort(rng.integers(lo, hi, nq)).astype(np.uint16)

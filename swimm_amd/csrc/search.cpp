@@ -350,6 +350,7 @@ struct SearchRun {
     std::vector<std::map<int, DbPlan>> stream_plans;         // streaming: work lists per (range, workgroup count), released when the search has drained
     // the launch plan
     Mode main_mode = Mode::F16;
+    int f16_thr = 2048;                     // binary16 first tier: results >= this are re-run as packed int16 (f16_exact_below)
     bool lane_room = false, many_short = false, alternate = false;
     std::vector<uint8_t> use_sp;            // queries that run through the score-profile kernel (option "sp_threshold")
     std::vector<size_t> qcode_off;          // ... and where their padded residue codes start in d_qcodes
@@ -635,7 +636,10 @@ int SearchRun::plan_queries()
     // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
     // query's end are zero, like the reference's dummy row 23
-    main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 ? Mode::F16 : Mode::PK16);
+    // (binary16 first tier: results below f16_exact_below(extend) are exact -- the pipeline kernel's column offsets take up to 127 of the
+    // 2048; with an extend penalty beyond 300 the tier would be exact below 1 100 only, and the int16 tier is the first)
+    main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 && f16_exact_below(c->extend_gap) >= 1100 ? Mode::F16 : Mode::PK16);
+    f16_thr = f16_exact_below(c->extend_gap);
     // a database with a long-sequence tail is searched with launch shapes that leave room for lane-systolic waves
     lane_room = false;
     longest_cols = 0;
@@ -813,7 +817,7 @@ int SearchRun::plan_queries()
         const uint32_t lane_rows = (uint32_t)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));
         // (a query's own profile serves the lane-systolic kernel -- tail, promotion re-runs -- and its own pipeline launches; a
         // member of a stack has neither when no alignment of it can leave the first tier's range)
-        const bool own_profile = stack_of[q] < 0 || (long)qm[q] * c->max_pos >= (main_mode == Mode::F16 ? 2048 : 32767);
+        const bool own_profile = stack_of[q] < 0 || (long)qm[q] * c->max_pos >= (main_mode == Mode::F16 ? f16_thr : 32767);
         qps[q].mpad = own_profile ? std::max(qps[q].mpad, lane_rows) : 0;
         qps[q].prof_off = prof_elems;
         prof_elems += (size_t)kCodes * qps[q].mpad;
@@ -1273,7 +1277,8 @@ int SearchRun::issue()
     return 0;
 }
 
-// Promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher): f16 results >= 2048 are
+// Promotion ladder (the reference's int8 -> int16 -> int32, CPUsearch.c:678-957, one rung higher): f16 results >= f16_thr (2048
+// less the pipeline kernel's largest column offset) are
 // re-run as packed int16 pairs, int16 results >= 32767 as int32 sequences; every re-run is a lane-systolic item (one wave per
 // alignment).  The queries climb the ladder in two batches -- the longer half (issued first: done while the shorter half's
 // kernels still run), then the rest -- and a batch climbs together: one scan per query into a shared list, ONE copy back,
@@ -1288,7 +1293,7 @@ int SearchRun::promotion_ladder()
     for (uint32_t k = 0; k < qn; ++k) {
         const uint32_t q = qn - 1 - k;
         const long bound = (long)qm[q] * c->max_pos;         // no alignment of this query can score more
-        if ((main_mode == Mode::F16 && bound >= 2048) || bound >= 32767) climbers.push_back(q);
+        if ((main_mode == Mode::F16 && bound >= f16_thr) || bound >= 32767) climbers.push_back(q);
     }
     const size_t half = climbers.size() >= 4 ? (climbers.size() + 1) / 2 : climbers.size();
     for (size_t b0 = 0; b0 < climbers.size(); b0 += std::max<size_t>(half, 1)) {
@@ -1297,7 +1302,7 @@ int SearchRun::promotion_ladder()
             HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_query[2 * q], 0));
             HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_query[2 * q + 1], 0));
         }
-        if (main_mode == Mode::F16 && ladder_rung(batch, 2048, Mode::PK16)) return 1;
+        if (main_mode == Mode::F16 && ladder_rung(batch, f16_thr, Mode::PK16)) return 1;
         if (ladder_rung(batch, 32767, Mode::I32)) return 1;
     }
     return 0;
@@ -1324,7 +1329,7 @@ int SearchRun::ladder_rung(const std::vector<uint32_t> &batch, int thr, Mode mod
         HIP_TRY(hipMemcpyAsync(counts.data(), c->d_ladder_counts.p, qs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream3));
         HIP_TRY(hipStreamSynchronize(c->stream3));
         const bool overflow = counts.back() > cap;
-        if (overflow && round > 1000) return fail("promotion ladder: the list of alignments that left the %s range does not drain", thr == 2048 ? "f16" : "int16");
+        if (overflow && round > 1000) return fail("promotion ladder: the list of alignments that left the %s range does not drain", thr != 32767 ? "f16" : "int16");
         const uint32_t total = std::min(counts.back(), cap);
         if (total) {
             std::vector<uint32_t> list(total);

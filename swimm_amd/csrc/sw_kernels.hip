@@ -147,6 +147,50 @@ __device__ __forceinline__ void cell2<OpsF16>(v2h &hd, v2h &H0, v2h &E0, v2h &H1
     asm("" : "+v"(best));
 }
 
+// The pipeline kernel's binary16 tier in COLUMN-OFFSET form: 6.5 packed ops + 1 v_perm_b32 per 2 cells instead of 7.5 + 1.
+// Every value of column j is stored with o_j = (j mod P) * ge added (H* = H + o_j, E* = E + o_j on entering column j,
+// F' = F + o_j + ge), and the profile is staged as S' = S + ge.  Then
+//     t* = Hdiag* + S'                 (the diagonal came from column j-1: o_{j-1} + ge = o_j)
+//     a  = F' - ge                     (= F + o_j)
+//     h* = max3(t*, E*, a)             (a >= o_j because F' >= fl = o_j + ge: the max with 0)
+//     u' = h* - (goe - ge)
+//     E* <- max(E*, u')                (E + o_{j+1}: the decay by ge is the offset's growth -- ONE op instead of two; E may
+//                                       fall below the floor, h* takes its floor from a)
+//     F' <- max3(a, u', fl)
+// and the running best is kept per column in offset space (max3 over two rows) and merged once per column as colbest - o_j.
+// Every P columns (f16_renorm_chunks) the registers H*, E* and the diagonal are taken back by P * ge.  Exactness: all
+// stored values are integers <= max(H) + o_max (+17 for t*, which never exceeds the new h*), so a result below
+// f16_exact_below(ge) = 2048 - o_max is exact, and the first value that leaves the exact range makes a result >= that
+// threshold -- the host re-runs those as packed int16, as before.
+__device__ __forceinline__ v2h pk_max_f16(v2h a, v2h b)
+{
+    v2h d;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));       // (asm: the builtin first canonicalises operands that came out of asm)
+    return d;
+}
+__device__ __forceinline__ void cell2_ofs(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2h &E1, v2h &Fp, v2h &colbest, v2h S0, v2h S1,
+                                          v2h ngo, v2h nge, v2h fl)
+{
+    v2h a0 = Fp + nge;
+    v2h t0 = hd + S0;
+    hd = H0;
+    v2h h0 = OpsF16::max3(t0, E0, a0);
+    H0 = h0;
+    v2h u0 = h0 + ngo;
+    E0 = pk_max_f16(E0, u0);
+    Fp = OpsF16::max3(a0, u0, fl);
+    v2h a1 = Fp + nge;
+    v2h t1 = hd + S1;
+    hd = H1;
+    v2h h1 = OpsF16::max3(t1, E1, a1);
+    H1 = h1;
+    v2h u1 = h1 + ngo;
+    E1 = pk_max_f16(E1, u1);
+    Fp = OpsF16::max3(a1, u1, fl);
+    colbest = OpsF16::max3(colbest, h0, h1);
+    asm("" : "+v"(colbest));
+}
+
 __host__ __device__ constexpr size_t round16(size_t x) { return (x + 15) & ~(size_t)15; }
 // +16: the 25 code rows start 16 bytes (mod 256) apart, so codes d and d' share LDS banks for
 // ds_read_b128 only when d == d' (mod 16)
@@ -286,9 +330,9 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 sx = (strip * T + r) >> 1;
             }
             uint32_t v = src[sx];
-            if (M == 2) {                           // int16 scores -> binary16
+            if (M == 2) {                           // int16 scores -> binary16, + ge (column-offset form, see cell2_ofs)
                 const v2s sv = as_v2s(v);
-                v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)sv.x, (_Float16)(float)sv.y});
+                v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.x + p.ge), (_Float16)(float)(sv.y + p.ge)});
             }
             *(uint32_t *)(prof_lds + d * PS + x * 4) = v;
         }
@@ -324,13 +368,20 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     it = __builtin_amdgcn_readfirstlane(it);
     int total = DYN ? 0x3fffffff : (int)p.wg_chunks[blockIdx.x];
 
+    constexpr bool OFS = M == 2;          // binary16 tier: column-offset form (cell2_ofs)
     const V goe = Ops::splat(M == 2 ? -p.goe : p.goe), ge = Ops::splat(M == 2 ? -p.ge : p.ge);
+    const V ngo = Ops::splat(-(p.goe - p.ge)), pge = Ops::splat(p.ge);          // OFS: -(open), +extend
+    const uint32_t renorm_chunks = OFS ? (uint32_t)f16_renorm_chunks(p.ge) : 0u;
+    const V nren = Ops::splat(-(int)(renorm_chunks * kChunkCols) * p.ge);          // OFS: what a renormalisation takes back
+    V off = Ops::zero(), fl = pge;                                                // OFS: o_j and o_j + ge of the coming column
+    uint32_t since = 0;                                                           // OFS: chunks of this item since the last renormalisation
+    const V left = OFS ? ge : Ops::zero();                                        // column -1: H = 0, stored with o_{-1} = -ge
     const unsigned char *my_prof = prof_lds + k * TP * 2;
 
     V H[T], E[T];
-    V best = Ops::zero(), diag_top = Ops::zero();
+    V best = Ops::zero(), diag_top = left;
 #pragma unroll
-    for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+    for (int r = 0; r < T; ++r) { H[r] = left; E[r] = Ops::zero(); }
 
     uint32_t cc = 0, nch = 0, seq0 = 0, half = 0, n = 0, next_it = kNoItem;
     uint32_t pass = 0, len = 0;            // RES: pass of the current item; steps the item-pass occupies (>= nch)
@@ -428,9 +479,10 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 // (wave 0 may read a column's boundary two steps after the last wave stored it at the earliest: the storing wave
                 // drains its stores at the top of its next step, below)
                 len = (RES && pass + 1 < passes && nch < (uint32_t)W + 1) ? (uint32_t)W + 1 : nch;
-                best = Ops::zero(); diag_top = Ops::zero();
+                best = Ops::zero(); diag_top = left;
 #pragma unroll
-                for (int r = 0; r < T; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+                for (int r = 0; r < T; ++r) { H[r] = left; E[r] = Ops::zero(); }
+                off = Ops::zero(); fl = pge; since = 0;
                 const int win = (int)((cur_q << 16) | pass);
                 if (RES && staged_win != win) {
                     // this wave's strip of the profile for this window: rows pass*W*T + k*T .. + T of the query's 25 codes.
@@ -446,7 +498,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         uint32_t v = *(volatile uint32_t *)(stage + idx);
                         if (M == 2) {
                             const v2s sv = as_v2s(v);
-                            v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)sv.x, (_Float16)(float)sv.y});
+                            v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.x + p.ge), (_Float16)(float)(sv.y + p.ge)});
                         }
                         if (idx < kCodes * (T / 2)) *(uint32_t *)(prof_lds + d * PS + (k * TP + 2 * x) * 2) = v;
                     }
@@ -476,6 +528,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             // top boundary of the strip for these columns: H of the row above, F entering row 0
             uint2 bin[C];
             const bool first_pass = RES ? pass == 0 : (bool)p.first_pass, last_pass = RES ? pass + 1 == passes : (bool)p.last_pass;
+            const bool zero_top = (k == 0 || seam) && (first_pass || seam);      // no row above: H = F = 0 (OFS: o_j and o_j + ge, set column by column)
             if (k == 0 || seam) {
                 if (first_pass || seam) {
 #pragma unroll
@@ -511,6 +564,16 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             // the column loop and every wave sat out its own prefetch, every step.)
             SWIMM_REQUEST_NEXT_CHUNK();
             STAMP(tB);
+            if constexpr (OFS) {
+                // the offsets have grown by ge per column for renorm_chunks chunks: take them back (2 T + 1 ops every 4 * renorm_chunks columns)
+                if (since == renorm_chunks) {
+#pragma unroll
+                    for (int r = 0; r < T; ++r) { H[r] = H[r] + nren; E[r] = E[r] + nren; }
+                    diag_top = diag_top + nren;
+                    off = Ops::zero(); fl = pge; since = 0;
+                }
+                ++since;
+            }
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) {
                 // The SIMD issues its OLDEST ready wave first, so waves that start a chunk together finish it one
@@ -525,6 +588,11 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 V hd = diag_top;
                 diag_top = Ops::from_bits(bin[jj].x);
                 V F = Ops::from_bits(bin[jj].y);
+                V colbest = off;                         // OFS: this column's best, in offset space (o_j = a true 0)
+                (void)colbest;
+                if constexpr (OFS) {
+                    if (zero_top) { diag_top = off; F = fl; }
+                }
 #pragma unroll
                 for (int r8 = 0; r8 < T / 8; ++r8) {
                     // one ds_read_b128 = the scores of 8 consecutive query rows for this lane's residue
@@ -537,6 +605,11 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         for (int q = 0; q < 4; ++q) {
                             // (A_r, B_r) pairs: low / high int16 of the two lookups
                             const int r = r8 * 8 + q * 2;
+                            if constexpr (OFS)
+                                cell2_ofs(hd, H[r], E[r], H[r + 1], E[r + 1], F, colbest,
+                                          Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
+                                          Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), ngo, ge, fl);
+                            else
                             cell2<Ops>(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
                                        Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
                                        Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
@@ -560,6 +633,11 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int r = rb + q * 2;
+                            if constexpr (OFS)
+                                cell2_ofs(hd, H[r], E[r], H[r + 1], E[r + 1], F, colbest,
+                                          Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
+                                          Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), ngo, ge, fl);
+                            else
                             cell2<Ops>(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
                                        Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
                                        Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
@@ -577,6 +655,11 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 const uint2 bout = make_uint2(Ops::bits(H[T - 1]), Ops::bits(F));
                 if (k < W - 1) ring[(size_t)((k * 2 + (c & 1)) * C + jj) * 64 + lane] = bout;
                 else if (!last_pass) p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = bout;
+                if constexpr (OFS) {
+                    best = pk_max_f16(best, colbest - off);       // the column's best without its offset
+                    asm("" : "+v"(best));
+                    off = fl; fl = fl + pge;                     // o_{j+1} = o_j + ge
+                }
                 // keep one column's lookups in flight at a time: without this fence the scheduler hoists
                 // all four columns' LDS reads and the kernel needs ~230 VGPRs (spills at 3 waves/SIMD)
                 __builtin_amdgcn_sched_barrier(0);

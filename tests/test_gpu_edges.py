@@ -93,6 +93,36 @@ def test_scores_on_the_promotion_thresholds(opts):
     assert stats["promoted"] >= 2              # 32767 and 32768 needed the int32 tier
 
 
+def _w_run(total):
+    """a sequence whose self score under BLOSUM62 is exactly `total` (W 11, C 9, H 8, A 4, K 5, P 7)"""
+    k, rest = divmod(total, 11)
+    filler = {0: "", 1: None, 2: None, 3: None, 4: "A", 5: "K", 6: None, 7: "P", 8: "H", 9: "C", 10: "KK"}[rest]
+    if filler is None:
+        k -= 1
+        filler = {12: "AH", 13: "AC", 14: "PP", 17: "CH"}[rest + 11]
+    return enc("W" * k + filler)
+
+
+@pytest.mark.parametrize("go,ge", [(10, 2), (5, 1), (11, 3), (4, 7), (12, 0), (3, 40)])
+@pytest.mark.parametrize("opts", [{}, {"tail_mode": 2}, {"tail_mode": 2, "rows_per_wave": 20, "waves": 4, "resident": 1}])
+def test_scores_around_the_binary16_tier_limit_for_any_extend_penalty(go, ge, opts):
+    """the pipeline kernel's binary16 tier stores column j with (j mod P) * extend added and is exact below 2048 less the largest
+    offset (sw_kernels.h, f16_exact_below): self scores on, just below and just above that limit and the old one, and homologs
+    with gaps whose scores sit in between, for several extend penalties (each has its own period P and limit)"""
+    period = 4 * (32 if ge <= 0 else max(1, 32 // ge))
+    limit = 2048 - (period - 1) * max(ge, 0)
+    targets = sorted(set([limit - 13, limit - 2, limit - 1, limit, limit + 1, limit + 2, 2040, 2047, 2048, 2050]))
+    seqs = [_w_run(t) for t in targets]
+    rng = np.random.default_rng(ge + 31)
+    for t in targets[:4]:                                # the same runs with an insertion and a deletion: gapped alignments near the limit
+        w = _w_run(t + 40)
+        seqs += [np.concatenate([w[:60], rnd(rng, 3), w[60:]]), np.delete(w, slice(100, 104))]
+    seqs += [rnd(rng, int(n)) for n in rng.integers(10, 260, 150)]
+    want, _ = run_case(seqs, [_w_run(t) for t in targets] + [_w_run(limit + 60)], go=go, ge=ge, opts=opts)
+    for t in targets:
+        assert (want == t).any(), t
+
+
 def test_chained_lane_passes_many_items():
     """every group through the lane-systolic kernel with 3 and 6 chained passes and thousands of items in
     flight: the inter-wave hand-over (boundary rows + progress counters through global memory) under load"""

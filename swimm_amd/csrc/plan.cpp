@@ -178,18 +178,18 @@ double plan_imbalance(swimm_hip_ctx *c, int n_wg)
 
 // Measured throughput (GCUPS of padded cells) of every launch shape of the f16-tier pipeline kernel: rows per wave
 // T = 8, 12, ... 36 (lines) by waves per workgroup W = 1..16 (columns), workgroups per CU by occupancy
-// (tools/plan_sweep.py --scale 1.0 on one MI355X, profiles/r02_plan_sweep.txt; round 1's table, before the next-chunk
-// prefetch, was 2-5 % lower and had the 8-wave shapes a little further behind the 4-wave ones).  W = 4, 8, 12, 16 put the same number of waves
+// (tools/plan_sweep.py --scale 1.0 on one MI355X, profiles/r03_plan_sweep.txt: the binary16 tier in column-offset form, 4-10 %
+// above round 2's table (profiles/r02_plan_sweep.txt) for every shape of four waves or more).  W = 4, 8, 12, 16 put the same number of waves
 // on each of the CU's 4 SIMDs; any other W runs like the next multiple of 4 (2 x 6 waves behave like 4+4+2+2).
 static const float kShapeGcups[8][16] = {
-    {2648, 4406, 5432, 6668, 6283, 6811, 7102, 7832, 6982, 6376, 6976, 7578, 6850, 6875, 5896, 7802},  // T=8
-    {3154, 4918, 6308, 7339, 6506, 6819, 7204, 8185, 7142, 6730, 7484, 8118, 7147, 7256, 7739, 8158},  // T=12
-    {3700, 5675, 6768, 8168, 6496, 5518, 7106, 8065, 5692, 6337, 6946, 7561, 6327, 6795, 7255, 7723},  // T=16
-    {3895, 5893, 6987, 8264, 5406, 6190, 7304, 8334, 5795, 6487, 7105, 7776, 6269, 7035, 7535, 8037},  // T=20
-    {4050, 6271, 7188, 8332, 5487, 6435, 7450, 8474, 5890, 6645, 7222, 7935, 6429, 7149, 7621, 8150},  // T=24
-    {4161, 6397, 7264, 8398, 6255, 6469, 7553, 8609, 6052, 6740, 7383, 8061, 6722, 7229, 7752, 8263},  // T=28
-    {4130, 6470, 6405, 8592, 4870, 5827, 6764, 7683, 6120, 6796, 7444, 8120, 0, 0, 0, 0},                 // T=32
-    {4144, 6660, 6398, 8523, 4902, 5900, 6674, 7809, 6154, 6874, 7083, 8217, 0, 0, 0, 0},                 // T=36
+    {2638, 4425, 5522, 6776, 6542, 7174, 7511, 8186, 7432, 6517, 7270, 7892, 7303, 7212, 6036, 8125},  // T=8
+    {3239, 5133, 6571, 8249, 7968, 7047, 7752, 8696, 7427, 7320, 8003, 8630, 6461, 6947, 7393, 7845},  // T=12
+    {3567, 5603, 7148, 8672, 7024, 6030, 7785, 8700, 5996, 6662, 7259, 7931, 6804, 7285, 7792, 8253},  // T=16
+    {3850, 6049, 7791, 8934, 5050, 6887, 7936, 8976, 6103, 6913, 7556, 8243, 6672, 7508, 7980, 8436},  // T=20
+    {4097, 6279, 7934, 9101, 5491, 6890, 8023, 9050, 6264, 7094, 7750, 8455, 6889, 7688, 8179, 8674},  // T=24
+    {4164, 6606, 7958, 9202, 6814, 7032, 8120, 9199, 6529, 7269, 7994, 8677, 7278, 7813, 8286, 8765},  // T=28
+    {4129, 6741, 8052, 9277, 5137, 6135, 7123, 8105, 6610, 7335, 8068, 8755, 0, 0, 0, 0},  // T=32
+    {4150, 6766, 6407, 9336, 5167, 6231, 6989, 8255, 6692, 7457, 7531, 8888, 0, 0, 0, 0},  // T=36
 };
 
 double shape_gcups(int T, int W) { return (T >= 8 && T <= 36 && T % 4 == 0 && W >= 1 && W <= 16) ? (double)kShapeGcups[(T - 8) / 4][W - 1] : 0.0; }

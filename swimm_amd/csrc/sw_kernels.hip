@@ -525,14 +525,27 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             } else {
                 wa = nwa; wb = nwb;
             }
+            if constexpr (OFS) {
+                // the offsets have grown by ge per column for renorm_chunks chunks: take them back (2 T + 1 ops every 4 * renorm_chunks columns)
+                if (since == renorm_chunks) {
+#pragma unroll
+                    for (int r = 0; r < T; ++r) { H[r] = H[r] + nren; E[r] = E[r] + nren; }
+                    diag_top = diag_top + nren;
+                    off = Ops::zero(); fl = pge; since = 0;
+                }
+                ++since;
+            }
             // top boundary of the strip for these columns: H of the row above, F entering row 0
             uint2 bin[C];
             const bool first_pass = RES ? pass == 0 : (bool)p.first_pass, last_pass = RES ? pass + 1 == passes : (bool)p.last_pass;
-            const bool zero_top = (k == 0 || seam) && (first_pass || seam);      // no row above: H = F = 0 (OFS: o_j and o_j + ge, set column by column)
             if (k == 0 || seam) {
-                if (first_pass || seam) {
+                if (first_pass || seam) {            // no row above: H = F = 0 (OFS: stored as o_j and o_j + ge)
+                    V o = off, f = fl;
 #pragma unroll
-                    for (int jj = 0; jj < C; ++jj) bin[jj] = make_uint2(0u, 0u);
+                    for (int jj = 0; jj < C; ++jj) {
+                        bin[jj] = OFS ? make_uint2(Ops::bits(o), Ops::bits(f)) : make_uint2(0u, 0u);
+                        if constexpr (OFS) { o = f; f = f + pge; }
+                    }
                 } else {
                     if (RES) {
                         // written by this workgroup's last wave one group length ago: the step barriers order the two,
@@ -564,16 +577,6 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             // the column loop and every wave sat out its own prefetch, every step.)
             SWIMM_REQUEST_NEXT_CHUNK();
             STAMP(tB);
-            if constexpr (OFS) {
-                // the offsets have grown by ge per column for renorm_chunks chunks: take them back (2 T + 1 ops every 4 * renorm_chunks columns)
-                if (since == renorm_chunks) {
-#pragma unroll
-                    for (int r = 0; r < T; ++r) { H[r] = H[r] + nren; E[r] = E[r] + nren; }
-                    diag_top = diag_top + nren;
-                    off = Ops::zero(); fl = pge; since = 0;
-                }
-                ++since;
-            }
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) {
                 // The SIMD issues its OLDEST ready wave first, so waves that start a chunk together finish it one
@@ -590,9 +593,6 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 V F = Ops::from_bits(bin[jj].y);
                 V colbest = off;                         // OFS: this column's best, in offset space (o_j = a true 0)
                 (void)colbest;
-                if constexpr (OFS) {
-                    if (zero_top) { diag_top = off; F = fl; }
-                }
 #pragma unroll
                 for (int r8 = 0; r8 < T / 8; ++r8) {
                     // one ds_read_b128 = the scores of 8 consecutive query rows for this lane's residue

@@ -74,10 +74,11 @@ struct PipeParams {
 };
 
 // The pipeline kernel's binary16 tier stores column j with an offset (j mod P) * ge (sw_kernels.hip, cell2_ofs) and takes the
-// offsets back every P = 4 * f16_renorm_chunks(ge) columns: at most 127 (3 ge when ge > 32) on top of a score.
+// offsets back every P = 4 * f16_renorm_chunks(ge) columns; the running best carries the COMING column's offset, so up to
+// P * ge (at most 128; 4 ge when ge > 32) sits on top of a score.
 __host__ __device__ constexpr int f16_renorm_chunks(int ge) { return ge <= 0 ? 32 : (32 / ge < 1 ? 1 : 32 / ge); }
 // ... so a first-tier result below this is exact, and anything that left the exact range shows as a result >= this
-constexpr int f16_exact_below(int ge) { return 2048 - (4 * f16_renorm_chunks(ge) - 1) * (ge > 0 ? ge : 0); }
+constexpr int f16_exact_below(int ge) { return 2048 - 4 * f16_renorm_chunks(ge) * (ge > 0 ? ge : 0); }
 
 enum class Mode { PK16, I32, F16 };   // F16: packed binary16 first tier (pipeline kernel only)
 

@@ -157,18 +157,18 @@ __device__ __forceinline__ void cell2<OpsF16>(v2h &hd, v2h &H0, v2h &E0, v2h &H1
 //     E* <- max(E*, u')                (E + o_{j+1}: the decay by ge is the offset's growth -- ONE op instead of two; E may
 //                                       fall below the floor, h* takes its floor from a)
 //     F' <- max3(a, u', fl)
-// and the running best is kept per column in offset space (max3 over two rows) and merged once per column as colbest - o_j.
+// and the running best lives in offset space too (best* = best + o_j: max3 over two rows as before, + ge once per column).
 // Every P columns (f16_renorm_chunks) the registers H*, E* and the diagonal are taken back by P * ge.  Exactness: all
-// stored values are integers <= max(H) + o_max (+17 for t*, which never exceeds the new h*), so a result below
-// f16_exact_below(ge) = 2048 - o_max is exact, and the first value that leaves the exact range makes a result >= that
-// threshold -- the host re-runs those as packed int16, as before.
+// stored values are integers <= max(H) + P * ge (the running best, which carries the coming column's offset; t* never exceeds
+// the new h*), so a result below f16_exact_below(ge) = 2048 - P * ge is exact, and the first value that leaves the exact
+// range makes a result >= that threshold -- the host re-runs those as packed int16, as before.
 __device__ __forceinline__ v2h pk_max_f16(v2h a, v2h b)
 {
     v2h d;
     asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));       // (asm: the builtin first canonicalises operands that came out of asm)
     return d;
 }
-__device__ __forceinline__ void cell2_ofs(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2h &E1, v2h &Fp, v2h &colbest, v2h S0, v2h S1,
+__device__ __forceinline__ void cell2_ofs(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2h &E1, v2h &Fp, v2h &best, v2h S0, v2h S1,
                                           v2h ngo, v2h nge, v2h fl)
 {
     v2h a0 = Fp + nge;
@@ -187,8 +187,8 @@ __device__ __forceinline__ void cell2_ofs(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2
     v2h u1 = h1 + ngo;
     E1 = pk_max_f16(E1, u1);
     Fp = OpsF16::max3(a1, u1, fl);
-    colbest = OpsF16::max3(colbest, h0, h1);
-    asm("" : "+v"(colbest));
+    best = OpsF16::max3(best, h0, h1);
+    asm("" : "+v"(best));
 }
 
 __host__ __device__ constexpr size_t round16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -525,27 +525,14 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             } else {
                 wa = nwa; wb = nwb;
             }
-            if constexpr (OFS) {
-                // the offsets have grown by ge per column for renorm_chunks chunks: take them back (2 T + 1 ops every 4 * renorm_chunks columns)
-                if (since == renorm_chunks) {
-#pragma unroll
-                    for (int r = 0; r < T; ++r) { H[r] = H[r] + nren; E[r] = E[r] + nren; }
-                    diag_top = diag_top + nren;
-                    off = Ops::zero(); fl = pge; since = 0;
-                }
-                ++since;
-            }
             // top boundary of the strip for these columns: H of the row above, F entering row 0
             uint2 bin[C];
             const bool first_pass = RES ? pass == 0 : (bool)p.first_pass, last_pass = RES ? pass + 1 == passes : (bool)p.last_pass;
+            const bool zero_top = (k == 0 || seam) && (first_pass || seam);      // no row above: H = F = 0 (OFS: o_j and o_j + ge, set column by column)
             if (k == 0 || seam) {
-                if (first_pass || seam) {            // no row above: H = F = 0 (OFS: stored as o_j and o_j + ge)
-                    V o = off, f = fl;
+                if (first_pass || seam) {
 #pragma unroll
-                    for (int jj = 0; jj < C; ++jj) {
-                        bin[jj] = OFS ? make_uint2(Ops::bits(o), Ops::bits(f)) : make_uint2(0u, 0u);
-                        if constexpr (OFS) { o = f; f = f + pge; }
-                    }
+                    for (int jj = 0; jj < C; ++jj) bin[jj] = make_uint2(0u, 0u);
                 } else {
                     if (RES) {
                         // written by this workgroup's last wave one group length ago: the step barriers order the two,
@@ -577,6 +564,16 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             // the column loop and every wave sat out its own prefetch, every step.)
             SWIMM_REQUEST_NEXT_CHUNK();
             STAMP(tB);
+            if constexpr (OFS) {
+                // the offsets have grown by ge per column for renorm_chunks chunks: take them back (2 T + 1 ops every 4 * renorm_chunks columns)
+                if (since == renorm_chunks) {
+#pragma unroll
+                    for (int r = 0; r < T; ++r) { H[r] = H[r] + nren; E[r] = E[r] + nren; }
+                    diag_top = diag_top + nren; best = best + nren;
+                    off = Ops::zero(); fl = pge; since = 0;
+                }
+                ++since;
+            }
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) {
                 // The SIMD issues its OLDEST ready wave first, so waves that start a chunk together finish it one
@@ -591,8 +588,11 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 V hd = diag_top;
                 diag_top = Ops::from_bits(bin[jj].x);
                 V F = Ops::from_bits(bin[jj].y);
-                V colbest = off;                         // OFS: this column's best, in offset space (o_j = a true 0)
-                (void)colbest;
+                if constexpr (OFS) {
+                    // (a real branch, wave-uniform: as a select it is two v_cndmask_b32 per column for every wave; setting the four
+                    // columns' values up ahead of the loop costs eight registers, which the 28-row kernel does not have)
+                    if (zero_top) { asm volatile(""); diag_top = off; F = fl; }
+                }
 #pragma unroll
                 for (int r8 = 0; r8 < T / 8; ++r8) {
                     // one ds_read_b128 = the scores of 8 consecutive query rows for this lane's residue
@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                             // (A_r, B_r) pairs: low / high int16 of the two lookups
                             const int r = r8 * 8 + q * 2;
                             if constexpr (OFS)
-                                cell2_ofs(hd, H[r], E[r], H[r + 1], E[r + 1], F, colbest,
+                                cell2_ofs(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
                                           Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
                                           Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), ngo, ge, fl);
                             else
@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         for (int q = 0; q < 2; ++q) {
                             const int r = rb + q * 2;
                             if constexpr (OFS)
-                                cell2_ofs(hd, H[r], E[r], H[r + 1], E[r + 1], F, colbest,
+                                cell2_ofs(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
                                           Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
                                           Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), ngo, ge, fl);
                             else
@@ -656,8 +656,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 if (k < W - 1) ring[(size_t)((k * 2 + (c & 1)) * C + jj) * 64 + lane] = bout;
                 else if (!last_pass) p.bnd[(bnd_off + (uint64_t)cc * C + jj) * 64 + lane] = bout;
                 if constexpr (OFS) {
-                    best = pk_max_f16(best, colbest - off);       // the column's best without its offset
-                    asm("" : "+v"(best));
+                    best = best + pge;                           // the best so far, in the next column's offset space
                     off = fl; fl = fl + pge;                     // o_{j+1} = o_j + ge
                 }
                 // keep one column's lookups in flight at a time: without this fence the scheduler hoists
@@ -670,7 +669,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             const bool scored = !RES ? cc + 1 == nch : cc + 1 == nch;
             if (scored) {   // item(-pass) finished: every strip contributes its best (CPUsearch.c:670-676)
                 if (M == 2) {
-                    const v2h b2 = __builtin_bit_cast(v2h, Ops::bits(best));
+                    const v2h b2 = __builtin_bit_cast(v2h, Ops::bits(best - off));      // (best* carries the coming column's offset)
                     atomicMax(q_out + seq0 + 2 * lane, (int)(float)b2.x);          // a lane's pair = two neighbours of the sorted database
                     atomicMax(q_out + seq0 + 2 * lane + 1, (int)(float)b2.y);
                 } else if (PK) {

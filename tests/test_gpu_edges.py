@@ -110,8 +110,8 @@ def test_scores_around_the_binary16_tier_limit_for_any_extend_penalty(go, ge, op
     offset (sw_kernels.h, f16_exact_below): self scores on, just below and just above that limit and the old one, and homologs
     with gaps whose scores sit in between, for several extend penalties (each has its own period P and limit)"""
     period = 4 * (32 if ge <= 0 else max(1, 32 // ge))
-    limit = 2048 - (period - 1) * max(ge, 0)
-    targets = sorted(set([limit - 13, limit - 2, limit - 1, limit, limit + 1, limit + 2, 2040, 2047, 2048, 2050]))
+    limit = 2048 - period * max(ge, 0)
+    targets = sorted(set([limit - 13, limit - 3, limit - 2, limit - 1, limit, limit + 1, limit + 2, limit + 3, 2040, 2047, 2048, 2050]))
     seqs = [_w_run(t) for t in targets]
     rng = np.random.default_rng(ge + 31)
     for t in targets[:4]:                                # the same runs with an insertion and a deletion: gapped alignments near the limit

@@ -76,7 +76,7 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, bool resident, i
     int regs = 0;
     if (kernel_regs(c, mode, T, resident, &regs)) return 1;
     const int waves_cu = 4 * regs_to_waves_per_simd(regs);
-    const size_t lds = pipe_lds_bytes(T, W, resident);
+    const size_t lds = pipe_lds_bytes(mode, T, W, resident);
     int n = std::min(waves_cu / W, (int)(163840 / lds));
     if (c->opt_wgs_per_cu > 0) n = c->opt_wgs_per_cu;
     *out = std::max(1, n);
@@ -178,18 +178,18 @@ double plan_imbalance(swimm_hip_ctx *c, int n_wg)
 
 // Measured throughput (GCUPS of padded cells) of every launch shape of the f16-tier pipeline kernel: rows per wave
 // T = 8, 12, ... 36 (lines) by waves per workgroup W = 1..16 (columns), workgroups per CU by occupancy
-// (tools/plan_sweep.py --scale 1.0 on one MI355X, profiles/r03_plan_sweep.txt: the binary16 tier in column-offset form, 4-10 %
-// above round 2's table (profiles/r02_plan_sweep.txt) for every shape of four waves or more).  W = 4, 8, 12, 16 put the same number of waves
+// (tools/plan_sweep.py --scale 1.0 on one MI355X, profiles/r03_plan_sweep.txt: the binary16 tier in column-offset form with the fused pair score,
+// 15-25 % above round 2's table (profiles/r02_plan_sweep.txt) for the shapes of four waves and more).  W = 4, 8, 12, 16 put the same number of waves
 // on each of the CU's 4 SIMDs; any other W runs like the next multiple of 4 (2 x 6 waves behave like 4+4+2+2).
 static const float kShapeGcups[8][16] = {
-    {2638, 4425, 5522, 6776, 6542, 7174, 7511, 8186, 7432, 6517, 7270, 7892, 7303, 7212, 6036, 8125},  // T=8
-    {3239, 5133, 6571, 8249, 7968, 7047, 7752, 8696, 7427, 7320, 8003, 8630, 6461, 6947, 7393, 7845},  // T=12
-    {3567, 5603, 7148, 8672, 7024, 6030, 7785, 8700, 5996, 6662, 7259, 7931, 6804, 7285, 7792, 8253},  // T=16
-    {3850, 6049, 7791, 8934, 5050, 6887, 7936, 8976, 6103, 6913, 7556, 8243, 6672, 7508, 7980, 8436},  // T=20
-    {4097, 6279, 7934, 9101, 5491, 6890, 8023, 9050, 6264, 7094, 7750, 8455, 6889, 7688, 8179, 8674},  // T=24
-    {4164, 6606, 7958, 9202, 6814, 7032, 8120, 9199, 6529, 7269, 7994, 8677, 7278, 7813, 8286, 8765},  // T=28
-    {4129, 6741, 8052, 9277, 5137, 6135, 7123, 8105, 6610, 7335, 8068, 8755, 0, 0, 0, 0},  // T=32
-    {4150, 6766, 6407, 9336, 5167, 6231, 6989, 8255, 6692, 7457, 7531, 8888, 0, 0, 0, 0},  // T=36
+    {2505, 4154, 5428, 6628, 6680, 8128, 7191, 8828, 6873, 7535, 8095, 8618, 6252, 6722, 7150, 7597},  // T=8
+    {3236, 5153, 6724, 8362, 7541, 6328, 8171, 9212, 6042, 6698, 7350, 7991, 7057, 7561, 7996, 8497},  // T=12
+    {3529, 5516, 7361, 9401, 6683, 7457, 8624, 9612, 6442, 7155, 7766, 8403, 7441, 8006, 8516, 9040},  // T=16
+    {3707, 5834, 7623, 9695, 7053, 7696, 8874, 9906, 6697, 7415, 8073, 8727, 7682, 8238, 8717, 9240},  // T=20
+    {3792, 6093, 7964, 10162, 7261, 7895, 9033, 10084, 6949, 7704, 8364, 9025, 7906, 8512, 9031, 9606},  // T=24
+    {3692, 5881, 8136, 10201, 7197, 7887, 9147, 10298, 6920, 7672, 8406, 9140, 8050, 8654, 9242, 9856},  // T=28
+    {3777, 6005, 8292, 10334, 7298, 7984, 9240, 10422, 7031, 7772, 8536, 9270, 0, 0, 0, 0},  // T=32
+    {3954, 6498, 8776, 10253, 5255, 6252, 7264, 8243, 7253, 8016, 8804, 9554, 0, 0, 0, 0},  // T=36
 };
 
 double shape_gcups(int T, int W) { return (T >= 8 && T <= 36 && T % 4 == 0 && W >= 1 && W <= 16) ? (double)kShapeGcups[(T - 8) / 4][W - 1] : 0.0; }
@@ -279,9 +279,9 @@ int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_
     bool ok[8] = {};
     auto rows_of = [](int m, int T, int W) { return (double)((m + T * W - 1) / (T * W)) * T * W; };
     // the group-resident instantiations against the per-pass ones the rate table was measured with (profiles/
-    // r03_resident_vs_per_pass_by_shape.txt): 1-2 % for every shape, once the 20-, 24- and 28-row ones no longer re-pack their E
-    // registers at every step (they lost 5-8 % until then; see the Makefile's -disable-promote-alloca-to-vector)
-    static const double kResidentFactor[8] = {1.0, 1.0, 0.993, 0.981, 0.991, 0.990, 0.984, 0.983};
+    // r03_resident_vs_per_pass_by_shape.txt, the fused-pair-score kernels): 3-4 % for every shape but the 32-row one, whose
+    // group-resident instantiation needs 135 registers (three waves per SIMD) where the per-pass one fits four in 125
+    static const double kResidentFactor[8] = {1.0, 1.0, 0.962, 0.967, 0.969, 0.973, 0.894, 0.960};
     auto rate_of = [&](int ti, int W) { return (double)kShapeGcups[ti][W - 1] * kResidentFactor[ti]; };
     for (int ti = 7; ti >= 0; --ti) {
         const int T = 8 + 4 * ti;

@@ -146,7 +146,7 @@ struct SpParams {
 };
 hipError_t launch_sp(int n_wg, const SpParams &p, hipStream_t s);
 
-size_t pipe_lds_bytes(int rows_per_wave, int waves, bool resident);
+size_t pipe_lds_bytes(Mode mode, int rows_per_wave, int waves, bool resident);
 // which (tier, rows per wave, hand-over scheme) kernels exist
 bool pipe_has_variant(Mode mode, int rows_per_wave);
 // registers / occupancy of one instantiation (for the host-side launch plan)

@@ -147,10 +147,10 @@ __device__ __forceinline__ void cell2<OpsF16>(v2h &hd, v2h &H0, v2h &E0, v2h &H1
     asm("" : "+v"(best));
 }
 
-// The pipeline kernel's binary16 tier in COLUMN-OFFSET form: 6.5 packed ops + 1 v_perm_b32 per 2 cells instead of 7.5 + 1.
+// The pipeline kernel's binary16 tier in COLUMN-OFFSET form: 6.5 packed ops per 2 cells instead of 7.5 + 1 v_perm_b32.
 // Every value of column j is stored with o_j = (j mod P) * ge added (H* = H + o_j, E* = E + o_j on entering column j,
 // F' = F + o_j + ge), and the profile is staged as S' = S + ge.  Then
-//     t* = Hdiag* + S'                 (the diagonal came from column j-1: o_{j-1} + ge = o_j)
+//     t* = Hdiag* + S'                 (the diagonal came from column j-1: o_{j-1} + ge = o_j; one v_pk_fma_f16, pair_score_plus)
 //     a  = F' - ge                     (= F + o_j)
 //     h* = max3(t*, E*, a)             (a >= o_j because F' >= fl = o_j + ge: the max with 0)
 //     u' = h* - (goe - ge)
@@ -168,11 +168,21 @@ __device__ __forceinline__ v2h pk_max_f16(v2h a, v2h b)
     asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));       // (asm: the builtin first canonicalises operands that came out of asm)
     return d;
 }
-__device__ __forceinline__ void cell2_ofs(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2h &E1, v2h &Fp, v2h &best, v2h S0, v2h S1,
-                                          v2h ngo, v2h nge, v2h fl)
+// t* for a lane's pair of sequences in ONE instruction.  The LDS profile of this tier holds a dword (S' , 1.0) per row and code;
+// xa / xb are the dwords of the pair's two residues:  lo = xa.lo * xb.hi + hd.lo = S'_a + hd.lo,  hi = xa.hi * xb.lo + hd.hi =
+// S'_b + hd.hi  (products by 1.0 and sums of small integers: exact).  It replaces the v_perm_b32 that interleaved two lookups
+// of a two-rows-per-dword profile, and the add: 6.5 ops per two cells instead of 7.5, for twice the LDS read traffic.
+__device__ __forceinline__ v2h pair_score_plus(uint32_t xa, uint32_t xb, v2h hd)
+{
+    v2h t;
+    asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(xa), "v"(xb), "v"(hd));
+    return t;
+}
+__device__ __forceinline__ void cell2_ofs(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2h &E1, v2h &Fp, v2h &best, uint32_t xa0, uint32_t xb0,
+                                          uint32_t xa1, uint32_t xb1, v2h ngo, v2h nge, v2h fl)
 {
     v2h a0 = Fp + nge;
-    v2h t0 = hd + S0;
+    v2h t0 = pair_score_plus(xa0, xb0, hd);
     hd = H0;
     v2h h0 = OpsF16::max3(t0, E0, a0);
     H0 = h0;
@@ -180,7 +190,7 @@ __device__ __forceinline__ void cell2_ofs(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2
     E0 = pk_max_f16(E0, u0);
     Fp = OpsF16::max3(a0, u0, fl);
     v2h a1 = Fp + nge;
-    v2h t1 = hd + S1;
+    v2h t1 = pair_score_plus(xa1, xb1, hd);
     hd = H1;
     v2h h1 = OpsF16::max3(t1, E1, a1);
     H1 = h1;
@@ -195,6 +205,9 @@ __host__ __device__ constexpr size_t round16(size_t x) { return (x + 15) & ~(siz
 // +16: the 25 code rows start 16 bytes (mod 256) apart, so codes d and d' share LDS banks for
 // ds_read_b128 only when d == d' (mod 16)
 __host__ __device__ constexpr int prof_row_bytes(int rows) { return rows * 2 + 16; }
+// the pipeline kernel's binary16 tier: a dword (score, 1.0) per row (pair_score_plus), four rows per ds_read_b128; the code rows
+// start an ODD number of 16-byte units apart, so that two codes share banks only when they are equal mod 16
+__host__ __device__ constexpr int prof_row_bytes_f16(int rows) { return rows * 4 + ((rows / 4) % 2 ? 32 : 16); }
 
 // a wave's strip of T rows occupies round8(T) rows of the LDS profile, so that its ds_read_b128 stay 16-byte aligned
 __host__ __device__ constexpr int strip_lds_rows(int T) { return (T + 7) & ~7; }
@@ -203,10 +216,10 @@ constexpr int kSeqRing = 32;      // item ids of the workgroup's sequence, publi
 // group-resident passes: per wave, a lane-linear landing area for the next pass's strip of the profile (filled by
 // global_load_lds, i.e. without registers)
 __host__ __device__ constexpr int strip_stage_dwords(int T) { return (kCodes * (T / 2) + 63) / 64 * 64; }
-size_t pipe_lds_bytes(int T, int W, bool resident)
+size_t pipe_lds_bytes(Mode mode, int T, int W, bool resident)
 {
-    return round16((size_t)kCodes * prof_row_bytes(strip_lds_rows(T) * W)) + (size_t)W * 2 * kChunkCols * 64 * sizeof(uint2) + (kSeqRing + 4) * 4 +
-           (resident ? (size_t)W * strip_stage_dwords(T) * 4 : 0);
+    const size_t prof = mode == Mode::F16 ? (size_t)kCodes * prof_row_bytes_f16(T * W) : (size_t)kCodes * prof_row_bytes(strip_lds_rows(T) * W);
+    return round16(prof) + (size_t)W * 2 * kChunkCols * 64 * sizeof(uint2) + (kSeqRing + 4) * 4 + (resident ? (size_t)W * strip_stage_dwords(T) * 4 : 0);
 }
 
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
@@ -299,7 +312,9 @@ template <int T, int M, bool DYN, bool RES>
 __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
 {
     static_assert(T % 4 == 0 && T >= 8, "strips are multiples of 4 rows");
-    constexpr int TP = strip_lds_rows(T);
+    constexpr bool OFS = M == 2;          // binary16 tier: column-offset form, one profile dword per row (cell2_ofs)
+    constexpr int TP = OFS ? T : strip_lds_rows(T);
+    constexpr int RB = OFS ? 4 : 2;       // bytes per row of the LDS profile
     constexpr bool PK = M != 1;
     typedef typename std::conditional<M == 0, OpsPK, typename std::conditional<M == 1, OpsI32, OpsF16>::type>::type Ops;
     typedef typename Ops::V V;
@@ -310,7 +325,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index = query strip
     const int lane = threadIdx.x & 63;
     const int RW = W * TP;
-    const int PS = prof_row_bytes(RW);
+    const int PS = OFS ? prof_row_bytes_f16(RW) : prof_row_bytes(RW);
     unsigned char *prof_lds = smem;
     uint2 *ring = (uint2 *)(smem + round16((size_t)kCodes * PS));
     uint32_t *seq = (uint32_t *)(ring + (size_t)W * 2 * C * 64);     // seq[n % kSeqRing]: id of the workgroup's n-th item
@@ -330,9 +345,11 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 sx = (strip * T + r) >> 1;
             }
             uint32_t v = src[sx];
-            if (M == 2) {                           // int16 scores -> binary16, + ge (column-offset form, see cell2_ofs)
+            if (M == 2) {                           // int16 scores -> (binary16 of score + ge, 1.0) per row (cell2_ofs, pair_score_plus)
                 const v2s sv = as_v2s(v);
-                v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.x + p.ge), (_Float16)(float)(sv.y + p.ge)});
+                *(uint2 *)(prof_lds + d * PS + x * 8) = make_uint2(__builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.x + p.ge), (_Float16)1.0f}),
+                                                                   __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.y + p.ge), (_Float16)1.0f}));
+                continue;
             }
             *(uint32_t *)(prof_lds + d * PS + x * 4) = v;
         }
@@ -368,7 +385,6 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     it = __builtin_amdgcn_readfirstlane(it);
     int total = DYN ? 0x3fffffff : (int)p.wg_chunks[blockIdx.x];
 
-    constexpr bool OFS = M == 2;          // binary16 tier: column-offset form (cell2_ofs)
     const V goe = Ops::splat(M == 2 ? -p.goe : p.goe), ge = Ops::splat(M == 2 ? -p.ge : p.ge);
     const V ngo = Ops::splat(-(p.goe - p.ge)), pge = Ops::splat(p.ge);          // OFS: -(open), +extend
     const uint32_t renorm_chunks = OFS ? (uint32_t)f16_renorm_chunks(p.ge) : 0u;
@@ -376,7 +392,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     V off = Ops::zero(), fl = pge;                                                // OFS: o_j and o_j + ge of the coming column
     uint32_t since = 0;                                                           // OFS: chunks of this item since the last renormalisation
     const V left = OFS ? ge : Ops::zero();                                        // column -1: H = 0, stored with o_{-1} = -ge
-    const unsigned char *my_prof = prof_lds + k * TP * 2;
+    const unsigned char *my_prof = prof_lds + k * TP * RB;
 
     V H[T], E[T];
     V best = Ops::zero(), diag_top = left;
@@ -498,8 +514,11 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         uint32_t v = *(volatile uint32_t *)(stage + idx);
                         if (M == 2) {
                             const v2s sv = as_v2s(v);
-                            v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.x + p.ge), (_Float16)(float)(sv.y + p.ge)});
-                        }
+                            if (idx < kCodes * (T / 2))
+                                *(uint2 *)(prof_lds + d * PS + (k * TP + 2 * x) * 4) =
+                                    make_uint2(__builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.x + p.ge), (_Float16)1.0f}),
+                                               __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.y + p.ge), (_Float16)1.0f}));
+                        } else
                         if (idx < kCodes * (T / 2)) *(uint32_t *)(prof_lds + d * PS + (k * TP + 2 * x) * 2) = v;
                     }
                     staged_win = win;
@@ -593,6 +612,22 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                     // columns' values up ahead of the loop costs eight registers, which the 28-row kernel does not have)
                     if (zero_top) { asm volatile(""); diag_top = off; F = fl; }
                 }
+                if constexpr (OFS) {
+#pragma unroll
+                    for (int g = 0; g < T / 4; ++g) {
+                        // one ds_read_b128 = the (score, 1.0) dwords of 4 consecutive query rows for one of the lane's two residues
+                        const uint4 a = *(const uint4 *)(pa + g * 16);
+                        const uint4 b = *(const uint4 *)(pb + g * 16);
+                        cell2_ofs(hd, H[4 * g], E[4 * g], H[4 * g + 1], E[4 * g + 1], F, best, a.x, b.x, a.y, b.y, ngo, ge, fl);
+                        cell2_ofs(hd, H[4 * g + 2], E[4 * g + 2], H[4 * g + 3], E[4 * g + 3], F, best, a.z, b.z, a.w, b.w, ngo, ge, fl);
+                        // How far ahead the scheduler may hoist a column's lookups (each is 4 registers until it is used), measured per strip
+                        // height (profiles/r03_plan_sweep.txt): unfenced up to 24 rows; the taller strips gain from a fence after every group of 4
+                        // rows (28 rows: 8 620 -> 10 220 GCUPS -- unfenced it spills; 32 rows: 10 100 -> 10 450 and 16 fewer registers, a fourth wave
+                        // per SIMD), 36 rows from one after every other group.
+                        constexpr int kFence = (T == 28 || T == 32) ? 1 : T == 36 ? 2 : 0;
+                        if (kFence && (g + 1) % (kFence ? kFence : 1) == 0 && g + 1 < T / 4) __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll
                 for (int r8 = 0; r8 < T / 8; ++r8) {
                     // one ds_read_b128 = the scores of 8 consecutive query rows for this lane's residue
@@ -605,11 +640,6 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         for (int q = 0; q < 4; ++q) {
                             // (A_r, B_r) pairs: low / high int16 of the two lookups
                             const int r = r8 * 8 + q * 2;
-                            if constexpr (OFS)
-                                cell2_ofs(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
-                                          Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
-                                          Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), ngo, ge, fl);
-                            else
                             cell2<Ops>(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
                                        Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
                                        Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
@@ -633,11 +663,6 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int r = rb + q * 2;
-                            if constexpr (OFS)
-                                cell2_ofs(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
-                                          Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
-                                          Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), ngo, ge, fl);
-                            else
                             cell2<Ops>(hd, H[r], E[r], H[r + 1], E[r + 1], F, best,
                                        Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x05040100u)),
                                        Ops::from_bits(__builtin_amdgcn_perm(bw[q], aw[q], 0x07060302u)), goe, ge);
@@ -651,6 +676,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         }
                     }
                 }
+                }   // (two-rows-per-dword profile of the integer tiers)
                 // bottom boundary of this column: to the next wave through LDS, or (last wave, more passes) to HBM
                 const uint2 bout = make_uint2(Ops::bits(H[T - 1]), Ops::bits(F));
                 if (k < W - 1) ring[(size_t)((k * 2 + (c & 1)) * C + jj) * 64 + lane] = bout;
@@ -744,7 +770,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
 template <int T, int M, bool DYN, bool RES>
 static hipError_t launch_one(int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
-    const size_t lds = pipe_lds_bytes(T, W, RES);
+    const size_t lds = pipe_lds_bytes(M == 0 ? Mode::PK16 : M == 1 ? Mode::I32 : Mode::F16, T, W, RES);
     hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, M, DYN, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((sw_pipe_kernel<T, M, DYN, RES>), dim3(n_wg), dim3(W * 64), lds, s, p);

@@ -1,5 +1,5 @@
 """The code objects, checked without a GPU: every pipeline / lane-systolic instantiation keeps its state in registers (no
-scratch), the binary16 tier's column loop has exactly its 4 x T v_perm_b32 and no 16-bit re-pack (round 3: the 20-, 24- and
+scratch), the binary16 tier's column loop has exactly its 4 x T v_pk_fma_f16, no v_perm_b32 and no 16-bit re-pack (round 3: the 20-, 24- and
 28-row group-resident instantiations carried T shifts + T perms at every step, 5-8 % of their throughput), and the register
 counts stay inside the occupancy class the planner's rate table was measured with."""
 import os
@@ -34,8 +34,8 @@ def test_binary16_column_loop_has_no_repack(isa):
         if k["kernel"] != "sw_pipe_kernel" or k["mode"] != 2:
             continue
         seen += 1
-        assert k["v_perm_b32"] == 4 * k["rows_per_wave"], k       # 4 columns per step, one interleave per row pair and residue pair
-        assert k["shifts_by_16"] == 0, k
+        assert k["v_pk_fma_f16"] == 4 * k["rows_per_wave"], k     # 4 columns per step, one fused pair-score + diagonal per row
+        assert k["v_perm_b32"] == 0 and k["shifts_by_16"] == 0, k
     assert seen == 24        # 8 strip heights x (static, dynamic, dynamic group-resident)
 
 

@@ -4,10 +4,11 @@ scratch bytes, and -- for the pipeline kernel's binary16 tier -- the `v_perm_b32
 
     make -C swimm_amd/csrc isa && python tools/check_isa.py [swimm_amd/csrc/obj/sw_kernels.s]
 
-The column loop of the binary16 tier needs exactly 4 columns x T `v_perm_b32` (the two residues' profile words interleaved) and
-no 16-bit shift at all.  Anything beyond that is a re-pack the compiler added: round 3 found T of each at the top of EVERY step in
-the 20-, 24- and 28-row group-resident instantiations (AMDGPUPromoteAllocaToVector had made the E[] register array one
-<2T x half> vector), 5-8 % of their throughput.  tests/test_codegen.py keeps that from coming back unnoticed.
+The column loop of the binary16 tier needs exactly 4 columns x T `v_pk_fma_f16` (a pair's two profile dwords + the diagonal,
+pair_score_plus), no `v_perm_b32` and no 16-bit shift at all (the integer tiers: 4 x T `v_perm_b32`).  Anything beyond that is a
+re-pack the compiler added: round 3 found T shifts + T perms at the top of EVERY step in the 20-, 24- and 28-row group-resident
+instantiations (AMDGPUPromoteAllocaToVector had made the E[] register array one <2T x half> vector), 5-8 % of their
+throughput.  tests/test_codegen.py keeps that from coming back unnoticed.
 """
 import json
 import os
@@ -29,7 +30,7 @@ def kernels(path):
         t = re.match(r"ILi(\d+)ELi(\d)ELb(\d)ELb(\d)E", rest)
         if kind == "sw_pipe_kernel" and t:
             rec.update(rows_per_wave=int(t.group(1)), mode=int(t.group(2)), dynamic=t.group(3) == "1", group_resident=t.group(4) == "1",
-                       v_perm_b32=len(re.findall(r"\bv_perm_b32", body)),
+                       v_perm_b32=len(re.findall(r"\bv_perm_b32", body)), v_pk_fma_f16=len(re.findall(r"\bv_pk_fma_f16", body)),
                        shifts_by_16=len(re.findall(r"v_lshrrev_b32_e32 v\d+, 16, v\d+", body)))
         t = re.match(r"ILi(\d)ELi(\d+)E", rest)
         if kind == "sw_lane_kernel" and t:

@@ -66,7 +66,7 @@ NUM_CU, SHADER_HZ = 256, 2.4e9
 #   (tools/microbench/valu_rate, profiles/r01_valu_issue_rates.txt: 4.2-4.5 measured in isolation, by occupancy)
 VALU_PEAK_SIMD_ISSUE = NUM_CU * 4 * SHADER_HZ / 2 / 1e9
 VALU_PEAK_CLASS = NUM_CU * 4 * SHADER_HZ / 4 / 1e9
-INSTR_PER_ROW, INSTR_PER_COLUMN = 8.5, 10          # model when no PMC profile matches: 7.5 packed-f16 ops + 1 v_perm per packed row; per-column overhead
+INSTR_PER_ROW, INSTR_PER_COLUMN = 6.5, 8           # model when no PMC profile matches: 6.5 packed-f16 ops per packed row (column-offset form, fused pair score); per-column overhead
 C4_SCALE = 1.3e9 / 6.99e9                          # the 1.3e9-residue Env-NR subsample of SURVEY 8d
 DEFAULT_SCALE = {"c2": 1.0, "c4": C4_SCALE, "c5": 0.25}
 
@@ -496,7 +496,7 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
                                    "source": f"SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, SQ_LDS_IDX_ACTIVE / ({NUM_CU} CUs x kernel cycles) of {prof['file']} (a committed profile of this plan, not this run)"}
             roofline_note = None
         # VALU instructions: from a committed SQ_INSTS_VALU summary of this configuration -- per launch when the plan and
-        # kernel are this run's (one query), per search for a query batch -- else from the 8.5-per-row model
+        # kernel are this run's (one query), per search for a query batch -- else from the 6.5-per-row model
         n_instr, instr_src = None, None
         for d in profs:
             if single_kernel and pipe_launches >= 1 and d.get("plan") == plan_key and d.get("kernel") == kernel_name and d.get("sq_insts_valu_per_launch"):
@@ -506,9 +506,9 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
                 n_instr = float(d["sq_insts_valu_per_search"])
                 instr_src = f"SQ_INSTS_VALU per search, all kernels, of {d['file']} (a committed profile of this configuration with the same launch plans, not this run)"
         if n_instr is None:
-            # wave-columns of query p = padded columns x waves x passes; each costs T x 8.5 + 10 instructions
+            # wave-columns of query p = padded columns x waves x passes; each costs T x 6.5 + 8 instructions
             n_instr = sum(float(my_padded) / 128 * p["waves"] * p["passes"] * (p["rows_per_wave"] * INSTR_PER_ROW + INSTR_PER_COLUMN) for p in plans)
-            instr_src = "model: 8.5 VALU instructions per packed row + 10 per column (no PMC profile of this configuration and plan under profiles/)"
+            instr_src = "model: 6.5 VALU instructions per packed row + 8 per column (no PMC profile of this configuration and plan under profiles/)"
         ginstr = n_instr / (k_ms_mean * 1e-3) / 1e9
         rec = {
             "value": round(gcups, 2), "unit": "GCUPS", "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),

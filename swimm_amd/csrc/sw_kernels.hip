@@ -207,6 +207,8 @@ __host__ __device__ constexpr size_t round16(size_t x) { return (x + 15) & ~(siz
 __host__ __device__ constexpr int prof_row_bytes(int rows) { return rows * 2 + 16; }
 // the pipeline kernel's binary16 tier: a dword (score, 1.0) per row (pair_score_plus), four rows per ds_read_b128; the code rows
 // start an ODD number of 16-byte units apart, so that two codes share banks only when they are equal mod 16
+// (ds_read_b64 lookups -- 32 bank pairs, no two codes on the same one, no bank conflicts at all -- were measured: c2 8 540 against
+// 9 680 GCUPS, every shape 8-15 % slower; only ds_read_b128 reaches the LDS's full rate)
 __host__ __device__ constexpr int prof_row_bytes_f16(int rows) { return rows * 4 + ((rows / 4) % 2 ? 32 : 16); }
 
 // a wave's strip of T rows occupies round8(T) rows of the LDS profile, so that its ds_read_b128 stay 16-byte aligned

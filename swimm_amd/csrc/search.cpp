@@ -858,7 +858,7 @@ int SearchRun::upload_profiles()
         const int8_t *qa = c->qcodes.data() + qdisp[q];
         for (int d = 0; d < kCodes; ++d) {
             int16_t *row = prof.data() + qps[q].prof_off + (size_t)d * qps[q].mpad;
-            for (uint32_t r = 0; r < qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + d];
+            for (uint32_t r = 0; r < qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + kHostCode[d]];     // (d: the device's residue numbering, sw_kernels.h)
         }
     }
     for (const Stack &st : stacks)
@@ -867,7 +867,7 @@ int SearchRun::upload_profiles()
             const int8_t *qa = c->qcodes.data() + qdisp[q];
             for (int d = 0; d < kCodes; ++d) {
                 int16_t *row = prof.data() + st.prof_off + (size_t)d * st.rows + (size_t)st.strip0[k] * st.T;
-                for (uint32_t r = 0; r < qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + d];
+                for (uint32_t r = 0; r < qm[q]; ++r) row[r] = c->submat[(int)qa[r] * 32 + kHostCode[d]];
             }
         }
     c->last_plans.resize(c->qm.size());
@@ -889,9 +889,9 @@ int SearchRun::upload_profiles()
         }
         if (!codes.empty()) {
             uint16_t sub16[kCodes * kSpSubStride] = {};      // [database residue d][query residue q]; d = 24 (lane padding) scores 0
-            for (int d = 0; d < 24; ++d)
-                for (int qr = 0; qr < 24; ++qr) {
-                    const _Float16 h = (_Float16)(float)c->submat[qr * 32 + d];
+            for (int d = 0; d < kCodes; ++d)
+                for (int qr = 0; qr < 24 && kHostCode[d] != 24; ++qr) {
+                    const _Float16 h = (_Float16)(float)c->submat[qr * 32 + kHostCode[d]];
                     memcpy(&sub16[d * kSpSubStride + qr], &h, sizeof(uint16_t));
                 }
             HIP_TRY(c->d_qcodes.reserve(codes.size()));

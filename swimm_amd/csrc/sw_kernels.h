@@ -7,6 +7,14 @@
 namespace swimm {
 
 constexpr int kCodes = 25;        // residue codes 0..24 (24 = lane padding), sequences.h:17-18
+// On the device the residues are RENUMBERED (by the two tiling kernels; every table a kernel indexes by a database residue --
+// query profiles, the score-profile kernel's matrix -- is built in that order by the host side).  Why: the profile row of code d
+// starts in LDS bank group d mod 16, a ds_read_b128 serves 8 lanes per clock, and two of them conflict when their codes are
+// equal mod 16 but different.  With the reference's alphabetical codes (A, S), (C, V), (F, Y), (D, W), (I, padding) ... share a
+// group: 2.1 % per pair of lanes for Robinson-Robinson frequencies, 45 % of all reads; with this order the sharing pairs are
+// (L, X) (A, Z) (G, U) (R, W) (I, C) (N, M) (Q, H) (F, Y) (B, padding): 1.0 %, 25 % of reads.
+constexpr uint8_t kDevCode[kCodes] = {1, 8, 20, 9, 10, 7, 2, 22, 4, 11, 0, 21, 5, 12, 6, 3, 13, 14, 15, 19, 16, 23, 17, 18, 24};     // reference code -> device code
+constexpr uint8_t kHostCode[kCodes] = {10, 0, 6, 15, 8, 12, 14, 5, 1, 3, 4, 9, 13, 16, 17, 18, 20, 22, 23, 19, 2, 11, 7, 21, 24};    // device code -> reference code
 constexpr int kGroupSeqs = 128;   // sequences per device group: 64 lanes x 2 packed int16 halves
 constexpr int kChunkCols = 4;     // DB columns per pipeline step (one dword per sequence)
 constexpr int kMaxWaves = 16;     // waves per workgroup (1024 threads)

@@ -1247,6 +1247,15 @@ hipError_t launch_lane(Mode mode, int rows_per_lane, int n_wg, const LaneParams 
 
 // ---- re-tile: reference chunk layout -> device groups --------------------------------------
 // reference byte of VL-group v, position j, lane kk: b[disp[v] + j*vl + kk]   (sequences.c:508-513)
+// reference residue code (0..24) -> device code (kDevCode), out of four 64-bit constants
+__device__ __forceinline__ uint32_t dev_code(uint32_t h)
+{
+    constexpr auto pack = [](int i0) { unsigned long long v = 0; for (int i = 0; i < 8 && i0 + i < kCodes; ++i) v |= (unsigned long long)kDevCode[i0 + i] << (8 * i); return v; };
+    constexpr unsigned long long t0 = pack(0), t1 = pack(8), t2 = pack(16), t3 = pack(24);
+    const unsigned long long t = h < 8 ? t0 : h < 16 ? t1 : h < 24 ? t2 : t3;
+    return (uint32_t)(t >> ((h & 7u) * 8)) & 0xffu;
+}
+
 // device dword of group g, chunk c, lane l: tiled[goff[g] + (c*64 + l)*8 + {0: seq 2l, 4: seq 2l+1}] -- a lane's pair are
 // NEIGHBOURS of the length-sorted database, so the lane-systolic kernel (one wave per pair, run to the longer member's
 // end) wastes nothing on the pair's shorter member: with (l, 64+l) the pairs of c3's three longest groups were 1.76 M
@@ -1280,7 +1289,7 @@ __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__r
                     if (code > 24) code = 24;         // out-of-alphabet bytes score like padding
                 }
                 if (code != 24) real_end = col + 1;
-                word |= code << (8 * jj);
+                word |= dev_code(code) << (8 * jj);
             }
             w[hh] = word;
             // true length of every sequence = 1 + its last non-padding column (the reference layout only
@@ -1335,14 +1344,15 @@ __global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const u
                     __builtin_memcpy(&x, codes + (size_t)b0 + col, 4);
                     const uint32_t over = ((x & 0x80808080u) | (((x & 0x7f7f7f7fu) + 0x67676767u) & 0x80808080u)) >> 7;   // 1 per byte > 24
                     const uint32_t m = over * 0xffu;
-                    word = (x & ~m) | (0x18181818u & m);
+                    x = (x & ~m) | (0x18181818u & m);
+                    word = dev_code(x & 0xffu) | dev_code((x >> 8) & 0xffu) << 8 | dev_code((x >> 16) & 0xffu) << 16 | dev_code(x >> 24) << 24;
                 } else {
                     word = 0;
 #pragma unroll
                     for (int jj = 0; jj < kChunkCols; ++jj) {
                         uint32_t code = 24;
                         if (col + jj < len) { code = codes[(size_t)b0 + col + jj]; if (code > 24) code = 24; }
-                        word |= code << (8 * jj);
+                        word |= dev_code(code) << (8 * jj);
                     }
                 }
             }

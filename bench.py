@@ -66,6 +66,7 @@ NUM_CU, SHADER_HZ = 256, 2.4e9
 #   (tools/microbench/valu_rate, profiles/r01_valu_issue_rates.txt: 4.2-4.5 measured in isolation, by occupancy)
 VALU_PEAK_SIMD_ISSUE = NUM_CU * 4 * SHADER_HZ / 2 / 1e9
 VALU_PEAK_CLASS = NUM_CU * 4 * SHADER_HZ / 4 / 1e9
+VALU_CLASS_MEASURED = NUM_CU * 4 * SHADER_HZ / 4.40 / 1e9     # that class in isolation, four waves per SIMD (profiles/r01_valu_issue_rates.txt: 4.40 cycles)
 INSTR_PER_ROW, INSTR_PER_COLUMN = 6.5, 8           # model when no PMC profile matches: 6.5 packed-f16 ops per packed row (column-offset form, fused pair score); per-column overhead
 C4_SCALE = 1.3e9 / 6.99e9                          # the 1.3e9-residue Env-NR subsample of SURVEY 8d
 DEFAULT_SCALE = {"c2": 1.0, "c4": C4_SCALE, "c5": 0.25}
@@ -523,6 +524,7 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
                               "peak": round(VALU_PEAK_SIMD_ISSUE, 1), "frac": round(ginstr / VALU_PEAK_SIMD_ISSUE, 4),
                               "peak_source": "MI355X_MICROARCH.md: 4 SIMDs per CU, one wave64 VALU instruction issued over 2 cycles",
                               "class_peak": round(VALU_PEAK_CLASS, 1), "class_frac": round(ginstr / VALU_PEAK_CLASS, 4),
+                              "class_measured_peak": round(VALU_CLASS_MEASURED, 1), "class_measured_frac": round(ginstr / VALU_CLASS_MEASURED, 4),
                               "class_source": ("VOP3P packed / 3-source ops issue over 4 cycles on gfx950 (profiles/r01_valu_issue_rates.txt); SQ_INSTS_VALU also counts the "
                                                "few 2-cycle scalar-operand ops of a column's overhead, so class_frac is a slight over-estimate of the packed pipe's use"),
                               "kernel_only_gcups": round(kernel_gcups, 2), "padded_cells": float(stats["cells"])},

@@ -122,7 +122,8 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    (the int16 / int32 first tiers have 16, 24, 32 only)
  *   "waves"          0 = chosen per query; 1..16 forces the wavefronts per workgroup;  "max_waves" caps them
  *   "wgs_per_cu"     0 = by occupancy;  "wg_limit" caps the persistent workgroups of a launch (0 = what the chip holds)
- *   "f16"            1 = default: packed binary16 first tier, exact below 2048, int16 and int32 re-runs above;
+ *   "f16"            1 = default: packed binary16 first tier, exact below 2048 - 128 (extend penalties up to 32; 2048 - 4 x extend
+ *                    beyond; with an extend penalty above 237 the int16 tier is the first), int16 and int32 re-runs above;
  *                    0 = packed int16 first tier
  *   "force_i32"      1 = everything in int32 (one sequence per lane)
  *   "tail_mode"      0 = auto: unusually long groups go through the lane-systolic kernel, 1 = every group, 2 = none

@@ -184,7 +184,7 @@ def test_short_query_batches_share_workgroups(seed):
     """Batches of 8 to 240 SHORT queries (1 to 90 rows, a few longer ones among them): queries of up to 72 rows are stacked
     two to four to a workgroup (a zero boundary at every seam, one score row per member) -- in group-resident batch launches
     on a database that is small beside the chip, in rotation over three streams on a larger one -- and every member's
-    whole score row must equal the checker's (a member of up to 72 rows cannot leave the binary16 range: 72 x 17 < 2048)."""
+    whole score row must equal the checker's (a member of up to 72 rows cannot leave the binary16 tier's exact range: 72 x 17 < 1920)."""
     rng = np.random.default_rng(9000 + seed)
     n = int(rng.choice([300, 1500, 6000, 30000, 120000]))
     L = np.clip(rng.lognormal(np.log(float(rng.choice([40, 150, 300]))), 0.6, n), 1, 2500).astype(np.int64)

@@ -435,20 +435,26 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
     all_ok, all_top_ok = bool(flags[0].item()), bool(flags[1].item())
 
     # ---- first search after a cold upload (the reference's workTime brackets the transfers, MICsearch.c:51,350) ----
-    cold_s = float("nan")
+    # Twice: the first one also pays for the device buffers of the streamed parts (hipMalloc; they go to the library's pool when the
+    # database is cleared), the second is what every later re-upload in the process costs.  Both are reported.
+    cold_s = cold_first_s = float("nan")
     if want_cold:
-        searcher.clear_db()
-        searcher.set_option("lazy_upload", 1)        # chunks stream in while the search runs (what swimm_hip_search_chunks does)
-        barrier()
-        t0 = time.perf_counter()
-        w["upload"](searcher)
-        exchange(*searcher.search_topr(TOP_R, w["n_valid"])[:2])
-        barrier()
-        cold_s = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([cold_s], dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            cold_s = float(tmax.item())
+        colds = []
+        for _ in range(2):
+            searcher.clear_db()
+            searcher.set_option("lazy_upload", 1)        # chunks stream in while the search runs (what swimm_hip_search_chunks does)
+            barrier()
+            t0 = time.perf_counter()
+            w["upload"](searcher)
+            exchange(*searcher.search_topr(TOP_R, w["n_valid"])[:2])
+            barrier()
+            dt = time.perf_counter() - t0
+            if dist is not None:
+                tmax = torch.tensor([dt], dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            colds.append(dt)
+        cold_first_s, cold_s = colds
 
     rec = None
     if rank == 0:
@@ -530,9 +536,11 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
                               "kernel_only_gcups": round(kernel_gcups, 2), "padded_cells": float(stats["cells"])},
             "search_call_ms": round(float(np.mean(wts)) * 1e3, 4),
             "value_incl_h2d": round(q_real * total_residues / cold_s / 1e9, 2) if want_cold else None,
-            "value_incl_h2d_note": (f"first search after a cold upload of the shard (pageable host memory, {w['upload_kind']}; chunk k+1 copied and tiled while chunk k is aligned), {cold_s * 1e3:.1f} ms"
-                                    if want_cold else None),
-            "h2d_upload_s": round(t_up, 3), "datagen_s": round(w["datagen_s"], 2), "searches_in_run": n_searches + (1 if want_cold else 0),
+            "value_incl_h2d_first": round(q_real * total_residues / cold_first_s / 1e9, 2) if want_cold else None,
+            "value_incl_h2d_note": (f"first search after a cold upload of the shard (pageable host memory, {w['upload_kind']}; chunk k+1 copied and tiled while chunk k is aligned): "
+                                    f"{cold_s * 1e3:.1f} ms with the device buffers coming from the library's pool (second cold upload of the process), "
+                                    f"{cold_first_s * 1e3:.1f} ms the first time (value_incl_h2d_first: fresh hipMalloc of the streamed parts)" if want_cold else None),
+            "h2d_upload_s": round(t_up, 3), "datagen_s": round(w["datagen_s"], 2), "searches_in_run": n_searches + (2 if want_cold else 0),
             "plans": plans if nq > 1 else None,
             "top1": [int(top_s[0][0]), int(top_i[0][0])],
             "bit_exact_vs_reference": all_ok, "merged_top20_matches_full_vectors": all_top_ok,

@@ -123,6 +123,55 @@ def test_scores_around_the_binary16_tier_limit_for_any_extend_penalty(go, ge, op
         assert (want == t).any(), t
 
 
+@pytest.mark.parametrize("path", ["chunks", "slabs"])
+@pytest.mark.parametrize("opts", [{}, {"tail_mode": 1}, {"tail_mode": 2, "f16": 0}, {"sp_threshold": 0}])
+def test_every_residue_code_on_both_upload_paths(path, opts):
+    """The device renumbers the residues when it tiles a chunk (retile_kernel) or a slab (tile_sequences_kernel, whose interior takes
+    four residues per dword and whose edges go byte by byte) and the host builds every lookup table in that order: all 24 codes --
+    the ambiguity codes and the dummy code 23 (J / O / U / *) included -- in the database and in the queries, against the
+    checker, through the pipeline kernel, the lane-systolic kernel, the int16 tier and the score-profile kernel.  Bytes above 24
+    in a database score like padding (0 against everything)."""
+    rng = np.random.default_rng(77)
+    seqs = [rng.integers(0, 24, int(n)).astype(np.int8) for n in rng.integers(1, 260, 300)]
+    seqs += [np.arange(24, dtype=np.int8), np.tile(np.arange(24, dtype=np.int8)[::-1], 9), np.full(37, 23, np.int8)]
+    queries = [np.arange(24, dtype=np.int8), np.tile(np.arange(24, dtype=np.int8), 5)[:101], rng.integers(0, 24, 333).astype(np.int8),
+               np.concatenate([seqs[7], seqs[100]])[:150]]
+    seqs = sorted(seqs, key=len)
+    lens = np.array([len(x) for x in seqs], dtype=np.uint16)
+    codes = np.concatenate(seqs).astype(np.int8)
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    dirty = codes.copy()                                   # the same database with stray bytes: they must score 0, i.e. like a residue
+    stray = rng.choice(len(codes), 40, replace=False)      # that matches nothing -- the checker sees code 24 (padding) there
+    dirty[stray] = rng.choice(np.array([25, 31, 64, 127], np.int8), 40)
+    clean_as_padding = codes.copy()
+    clean_as_padding[stray] = 24
+    queries = sorted(queries, key=len)
+    m = np.array([len(q) for q in queries], dtype=np.uint16)
+    disp = np.concatenate([[0], np.cumsum(m)]).astype(np.uint32)
+    a = np.concatenate(queries).astype(np.int8)
+    sm = submat.table("blosum50")
+    for db, seen_by_checker in ((codes, codes), (dirty, clean_as_padding)):
+        ch = None
+        with hip_backend.HipSearcher(0) as s:
+            for k, v in opts.items():
+                s.set_option(k, v)
+            s.set_queries(a, m, disp, sm, 11, 1)
+            if path == "chunks":
+                ch = host.Chunks(lens, db, 128, 30000)
+                for c in ch.chunks:
+                    s.add_chunk(c["b"], c["n"], c["disp"], 128, c["first_group"])
+                stride = ch.vc * 128
+            else:
+                for s0, s1 in ((0, 128), (128, 256), (256, len(lens))):
+                    s.add_sequences(lens[s0:s1], db[offs[s0]:offs[s1]], first_seq=s0)
+                stride = (len(lens) + 127) // 128 * 128
+            got, _ = s.search(stride)
+        if ch is not None:
+            ch.close()
+        want = np.array([[port.pair_score(q, seen_by_checker[offs[i]:offs[i + 1]], sm, 11, 1) for i in range(len(lens))] for q in queries], dtype=np.int32)
+        assert np.array_equal(got[:, :len(lens)], want), (path, opts, np.argwhere(got[:, :len(lens)] != want)[:5])
+
+
 def test_chained_lane_passes_many_items():
     """every group through the lane-systolic kernel with 3 and 6 chained passes and thousands of items in
     flight: the inter-wave hand-over (boundary rows + progress counters through global memory) under load"""

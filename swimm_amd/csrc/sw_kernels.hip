@@ -7,8 +7,9 @@
 //
 // How it is mapped here (not a translation of the SSE/AVX2/KNC loops):
 //   * one wavefront lane owns TWO database sequences, packed 2 x 16 bit in every VGPR, so one wave aligns 128
-//     sequences.  First tier: packed binary16 integers (v_pk_add_f16 / v_pk_maximum3_f16, exact below 2048);
-//     alignments that reach 2048 are re-run as packed int16 (v_pk_add_i16 clamp / v_pk_max_i16 /
+//     sequences.  First tier: packed binary16 integers (v_pk_fma_f16 / v_pk_add_f16 / v_pk_maximum3_f16; exact below
+//     f16_exact_below(extend), 1920 for extend 2: the pipeline kernel stores values with column offsets, cell2_ofs);
+//     alignments that reach that limit are re-run as packed int16 (v_pk_add_i16 clamp / v_pk_max_i16 /
 //     v_pk_sub_u16 clamp), those that reach 32767 in int32 -- the reference's int8 -> int16 -> int32 ladder
 //     (CPUsearch.c:678-957) one rung higher: CDNA4 has no packed int8 VALU;
 //   * sw_pipe_kernel: a workgroup is a systolic pipeline of W waves over the QUERY: wave k owns query rows
@@ -17,8 +18,10 @@
 //     longer than W*T rows does a boundary row go through HBM, once per pass (the "strip" traffic of SURVEY.md 8d
 //     with T_eff = W*T);
 //   * the substitution lookup is a query profile staged in LDS, prof[d][row]: one ds_read_b128 fetches the scores
-//     of 8 consecutive query rows for a lane's residue d; the two sequences' halves are combined by v_perm_b32.
-//     The 25 code rows sit 16 bytes (mod 256) apart, so two residues share LDS banks only if they are equal mod 16;
+//     of 8 consecutive query rows for a lane's residue d and the two sequences' halves are combined by v_perm_b32
+//     (integer tiers), or -- binary16 tier -- the (score, 1.0) dwords of 4 rows, the pair being formed inside the
+//     v_pk_fma_f16 that adds the diagonal (pair_score_plus).  The 25 code rows sit an odd number of 16-byte units
+//     apart, so two residues share LDS banks only if their (device) codes are equal mod 16;
 //   * workgroups are persistent and align device groups back to back as ONE continuous column stream (the pipeline
 //     fills and drains once per launch); which group comes next is decided by a longest-first queue (first two
 //     rounds dealt, then one global cursor) -- see the kernel;
@@ -77,7 +80,8 @@ struct OpsI32 {
 
 // ---- cell arithmetic, packed 2 x f16: exact while every H <= 2047 (integers up to 2048 are exact in
 // binary16; a sum that would leave that range makes some H >= 2048, which the host detects on the final
-// score and re-runs in int16).  Buys v_pk_maximum3_f16 (gfx950): 8.5 instead of 10 VALU ops per 2 cells.
+// score and re-runs in int16).  Buys v_pk_maximum3_f16 (gfx950): 8.5 instead of 10 VALU ops per 2 cells.  This plain form
+// serves the lane-systolic kernel; the pipeline kernel's binary16 tier uses cell2_ofs below (6.5).
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 struct OpsF16 {
     typedef v2h V;

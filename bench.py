@@ -613,6 +613,11 @@ def main():
                 r2, ok2 = run_workload(env, args, name, DEFAULT_SCALE[name] * args.secondary_scale, args.secondary_steps, 1, 10.0, not args.no_cold, baseline)
                 all_ok = all_ok and ok2
                 r2["workload"] = name
+                # (the line must stay well inside what a caller keeps of stdout -- gpurun: 24 000 characters: the texts that the top-level
+                # record already carries are not repeated)
+                for obj, keys in ((r2.get("roofline") or {}, ("note",)), (r2["valu_roofline"], ("peak_source", "class_source"))):
+                    for k in keys:
+                        obj.pop(k, None)
                 secondary.append(r2)
             extra["secondary"] = secondary
             c5 = secondary[1]

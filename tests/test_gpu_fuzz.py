@@ -1,6 +1,6 @@
 """Randomised parity: databases, query batches, penalties, upload paths and library options drawn from a seed, the whole
 score matrix against the CPU checker (the reference's AVX2 path when oracle/_ref is built).  Every seed is a fixed
-case; a failure names the seed and the options.  SWIMM_FUZZ_FIRST / SWIMM_FUZZ_SEEDS widen the sweep (default: seeds 0..159)."""
+case; a failure names the seed and the options.  SWIMM_FUZZ_FIRST / SWIMM_FUZZ_SEEDS widen the sweep (default: seeds 0..159), SWIMM_FUZZ_GE_MAX the extend penalties (default 0..5)."""
 import os
 
 import numpy as np
@@ -42,7 +42,7 @@ def draw_case(seed):
     disp = np.concatenate([[0], np.cumsum(m.astype(np.int64))]).astype(np.uint32)
     w = {"lengths": L, "codes": codes, "offs": offs, "n": n, "residues": total, "a": np.concatenate(queries), "m": m, "disp": disp,
          "query_residues": int(m.astype(np.int64).sum()), "matrix": str(rng.choice(MATRICES))}
-    go, ge = int(rng.integers(0, 21)), int(rng.integers(0, 6))
+    go, ge = int(rng.integers(0, 21)), int(rng.integers(0, int(os.environ.get("SWIMM_FUZZ_GE_MAX", "6"))))     # (the binary16 tier's offset period depends on ge)
     opts = {}
     pool = [("resident", [0, 1]), ("dynamic", [0]), ("tail_mode", [1, 2]), ("f16", [0]), ("force_i32", [1]), ("wg_limit", [4, 64]),
             ("bnd_mib", [1]), ("alternate", [0]), ("split", [0]), ("rotate", [0]), ("lane_rows", [0]), ("score_mib", [1]), ("tail_frac", [10, 200]),

@@ -335,7 +335,7 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
     dist, world, rank = env.dist, env.world, env.rank
     w = make_workload(env, name, scale)
     searcher = hip_backend.HipSearcher(env.dev_index)
-    for k, v in (("rows_per_wave", args.rows_per_wave), ("max_waves", args.max_waves), ("wgs_per_cu", args.wgs_per_cu)):
+    for k, v in (("rows_per_wave", args.rows_per_wave), ("max_waves", args.max_waves)):
         if v:
             searcher.set_option(k, v)
     searcher.set_option("time_launches", 1)      # HIP events around every pipeline launch, on the stream it runs on
@@ -585,7 +585,6 @@ def main():
     ap.add_argument("--no-cold", action="store_true", help="skip the first-search-after-a-cold-upload measurement (profiling runs: only the resident search's launches in the trace)")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--max-waves", type=int, default=0)
-    ap.add_argument("--wgs-per-cu", type=int, default=0)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -117,56 +117,35 @@ int swimm_hip_last_launch_ms(swimm_hip_ctx *ctx, double *sum_ms, uint32_t *launc
  * without guessing.  Measurement aid only (row (d) of SURVEY.md section 8); no reference counterpart. */
 int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t buf_len);
 
-/* Tuning knobs (optional).  key:
+/* Tuning knobs (optional; 20 keys).  What stays is what a parity test uses as a decomposition cut (the result must not depend on it), what
+ * the `swimm` program maps a command-line flag to, and the measurement aid; everything else the planner decides.  key:
  *   "rows_per_wave"  0 = launch shape chosen per query (default); 8, 12, ... 36 forces the rows per wavefront
  *                    (the int16 / int32 first tiers have 16, 24, 32 only)
  *   "waves"          0 = chosen per query; 1..16 forces the wavefronts per workgroup;  "max_waves" caps them
- *   "wgs_per_cu"     0 = by occupancy;  "wg_limit" caps the persistent workgroups of a launch (0 = what the chip holds)
- *   "f16"            1 = default: packed binary16 first tier, exact below 2048 - 128 (extend penalties up to 32; 2048 - 4 x extend
- *                    beyond; with an extend penalty above 237 the int16 tier is the first), int16 and int32 re-runs above;
- *                    0 = packed int16 first tier
+ *   "wg_limit"       caps the persistent workgroups of a launch (0 = what the chip holds)
+ *   "f16"            1 = default: packed binary16 first tier, exact below 2048 - P * extend with P = 4 * max(1, floor(32 / extend)) columns
+ *                    between two renormalisations (1920 for extend 2, 1928 for 3, 1923 for 5; with an extend penalty above 237 that
+ *                    limit falls below 1100 and the int16 tier is the first), int16 and int32 re-runs above; 0 = packed int16 first tier
  *   "force_i32"      1 = everything in int32 (one sequence per lane)
  *   "tail_mode"      0 = auto: unusually long groups go through the lane-systolic kernel, 1 = every group, 2 = none
  *   "tail_frac"      a group is "unusually long" above this percentage of a CU's mean load (default 30) ...
  *   "tail_cap"       ... and joins the lane-systolic tail as long as the tail stays below this many per mille of the search's cells
  *                    (default 25; 0 = no cap)
  *   "dynamic"        1 = default: workgroups pull groups from a global queue; 0 = static longest-first partition
- *   "lane_rows"      1 = default: one-pass lane-systolic launches of short queries use 2 / 4 query rows per lane; 0 = always 8
  *   "resident"       group-resident batch launches (ONE launch per launch shape for all the queries that share it: each workgroup
  *                    takes a (group, query) item through all its passes back to back, the strip boundary in scratch only it
  *                    touches; no launch boundary).  -1 = default: formed when the call has two or more
  *                    queries (or streams its database in) and the database is small beside the chip; 0 = never: one launch
- *                    per pass of every query ("split", "bnd_mib" apply); 1 = always, every query joins
- *   "batch_order"    0 = default: a group-resident batch hands its (group, query) items out group by group; 1 = a batch of one-pass queries
- *                    query by query (a workgroup keeps its strip of the profile from item to item).  Measured equal (300 queries of
- *                    80-120 residues x 1.0e8 residues: 7 245 against 7 270 GCUPS): the per-item profile switch is not what a batch of
- *                    one-pass queries loses against per-pass launches on a large database
+ *                    per pass of every query ("bnd_mib" applies); 1 = always, every query joins
  *   "sp_threshold"   65536 = default (none): queries of at least this many rows are aligned by the SCORE-PROFILE kernel instead of the
  *                    query-profile pipeline (the reference's query_length_threshold: `-p S` = 0, `-p Q` = none, `-p A -u N` = N,
  *                    MICsearch.c:39-43, swimm.c:81-85).  Exact like every path; slower on gfx950 at every query length
- *   "bulk_streams"   0 = default (two): the streams the passes of consecutive multi-pass queries take turns on; 1..4 = that many
- *                    (three and four measured slower: the further streams share hardware queues with the ones in use)
  *   "cut"            35 = default: per device group, the longest pairs leave the group (they run whole through the lane-systolic kernel
  *                    beside the pipeline kernel, which then stops at the longest pair left) when that saves more padded pipeline
  *                    cells than value/10 times the pairs' own cells; 0 = never
- *   "tall"           0 = default; 1 = a batch of queries for which the 4-wave group-resident batch is not formed (its longest item would
- *                    outlast the search) runs as ONE group-resident launch of tall workgroups (12 waves x 24 rows, one per CU, the
- *                    lane-systolic tail beside it); -1 = when that is estimated to be faster.  Measured slower than launches per pass
- *                    (c3 at 10 % of its size: 4 990 against 6 000 GCUPS): an A/B option, not a default
- *   "upload_head"    1 = default: a search that streams its database in for up to four queries sends the chunk with the shortest
- *                    sequences first, in parts of 16 MiB, 32 MiB and the rest (the chip is full 0.4 ms after the call), then the
- *                    database in descending order; 0 = descending order, whole chunks
  *   "stack"          1 = default: short queries (up to 72 rows) of a batch share workgroups -- two to four of them stacked along the
  *                    strips of one 4-wave workgroup, each with its own score row -- instead of padding each to a launch
  *                    shape of its own; 0 = every query its own workgroups
- *   "lane_room"      -1 = default: launch shapes leave a lane-systolic wave its registers when the database has a long-sequence
- *                    tail; 0 = never; 1 = always
- *   "rotate"         1 = default: when no group-resident batch is formed, eight or more one-pass queries run whole on three
- *                    streams in rotation; 0 = one stream
- *   "alternate"      1 = default: in a batch with two or more multi-pass queries, consecutive queries run their passes on two
- *                    streams, so that the end of every launch is covered by a kernel of the other query; 0 = one stream
- *   "split"          1 = default: a query of three or more passes runs the even- and odd-ranked groups as two kernels on two streams,
- *                    so that the end of one launch is covered by the other; 0 = one kernel per pass
  *   "time_launches"  1 = bracket every pipeline launch with events (swimm_hip_last_launch_ms); default 0
  *   "lazy_upload"    0 = default: add_chunk / add_sequences copy the caller's buffers before they return; 1 = they only
  *                    record them and the next search streams the chunks in, copying and tiling chunk k+1 while chunk k
@@ -176,14 +155,14 @@ int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t
  *                    searches, joined by swimm_hip_destroy); the calls of one context still come from one thread at a time.
  *   "upload_piece_kib"  with lazy_upload, chunks and slabs larger than this are recorded in pieces of about this size (default
  *                    98304 = 96 MiB), so that a database handed over as one buffer still streams in as several ranges
- *   "lane_acquire"   0 = default: chained lane-systolic passes read their predecessor's boundary rows with sc1 loads behind a
- *                    relaxed poll; 1 = an agent-scope acquire after every poll as well (A/B option)
  *   "score_mib"      HBM budget of the score rows (4 B per query and sequence): the query list is walked in batches
  *                    that fit (default 32768; 0 = one query per batch)
  *   "bnd_mib"        HBM budget of the pass-boundary buffer of multi-pass queries (4x the tiled residue bytes of the
  *                    groups in flight): the group list is cut into runs that fit (default 16384)
  * Unknown key -> error.  The environment variable SWIMM_HIP_OPTIONS="key=value,key=value" applies the same knobs to
- * every context at creation (for swimm_hip_search_chunks and the `swimm` program, whose contexts the caller never sees). */
+ * every context at creation (for swimm_hip_search_chunks and the `swimm` program, whose contexts the caller never sees).
+ * (Rounds 1-3 carried eleven more -- rotate, alternate, split, lane_rows, lane_room, wgs_per_cu, and the measured-and-rejected
+ * tall, batch_order, bulk_streams, lane_acquire, upload_head=0; their measurements are in profiles/NOTES.md.) */
 int swimm_hip_set_option(swimm_hip_ctx *ctx, const char *key, int value);
 
 /* Whole-call drop-in with the argument list of mic_search_knc_ap_multiple_chunks

@@ -78,7 +78,6 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, bool resident, i
     const int waves_cu = 4 * regs_to_waves_per_simd(regs);
     const size_t lds = pipe_lds_bytes(mode, T, W, resident);
     int n = std::min(waves_cu / W, (int)(163840 / lds));
-    if (c->opt_wgs_per_cu > 0) n = c->opt_wgs_per_cu;
     *out = std::max(1, n);
     return 0;
 }
@@ -553,7 +552,7 @@ bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &pl, size
     // (two passes gain nothing: measured -0.3 % on c2; neither do long passes, whose end is a small part of them: c2 with
     // 3 passes of 9 ms each 27.15 ms split, 26.97 ms not -- the split is for passes of up to ~5 ms at 8 000 GCUPS)
     const double pass_cells = (double)pl.total_chunks * kChunkCols * kGroupSeqs * qp.T * qp.W;
-    return c->opt_dynamic && c->opt_split && qp.passes > 2 && n_segs == 1 && pl.n_wg >= 2 && pl.split_n[1] >= (uint32_t)pl.n_wg && pass_cells < 4e10;
+    return c->opt_dynamic && qp.passes > 2 && n_segs == 1 && pl.n_wg >= 2 && pl.split_n[1] >= (uint32_t)pl.n_wg && pass_cells < 4e10;
 }
 
 

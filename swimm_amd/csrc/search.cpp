@@ -53,9 +53,6 @@ int run_resident_batch(swimm_hip_ctx *c, Mode mode, int T, int W, const Plan &pl
     p.queue = c->d_queue.p + c->queue_next++;
     p.qdesc = qd;
     p.n_queries = nq;
-    // (a batch of one-pass queries in query-major order: consecutive items of a workgroup are consecutive groups of one query, and
-    // its waves keep their strip of the profile from item to item; with multi-pass queries every item-pass switches the window anyway)
-    p.n_groups = (c->opt_batch_order && max_passes == 1 && nq > 1) ? pl.n_items : 0;
     p.wave_out = c->d_wave_out.p;
     p.bnd_wg_cols = pl.queue_cols[0];
     p.r0 = 0;
@@ -214,13 +211,14 @@ int run_sp_passes(swimm_hip_ctx *c, const QueryPlan &qp, const Plan &pl, const i
 // down a lane's rows is the step latency), everything else 8
 int lane_rows_for(const swimm_hip_ctx *c, uint32_t m)
 {
-    if (!c->opt_lane_rows) return kLaneRows;
+    (void)c;
     return m <= 128 ? 2 : m <= 256 ? 4 : kLaneRows;
 }
 
-// at most this many boundary columns (8 B each, two buffers) per lane-systolic launch: a batch that needs more is cut
-// into launches that follow each other on the stream
-static const uint64_t kLaneBndColsMax = (uint64_t)1 << 30;
+// at most this many boundary columns (8 B each, two buffers: 1 GiB + 1 GiB) per lane-systolic launch: a batch that needs more
+// is cut into launches that follow each other on the stream (the chains of a few dozen queries side by side already hide
+// each other's latency; a single query whose list is longer than this still gets what it needs)
+static const uint64_t kLaneBndColsMax = (uint64_t)1 << 27;
 
 // ONE lane-systolic launch for a batch of queries over the same item list (the long-sequence tail of a range, or the
 // promotion re-runs of one query): every (query, pass) is a set of workgroups with a work cursor of its own, the passes
@@ -297,7 +295,6 @@ int run_lane_batch(swimm_hip_ctx *c, Mode mode, int rows_per_lane, const std::ve
         p.goe = c->open_gap + c->extend_gap;
         p.ge = c->extend_gap;
         p.err = c->d_err.p;
-        p.agent_acquire = c->opt_lane_acquire;
         HIP_TRY(hipMemsetAsync(sc.queue.p, 0, pass_total * sizeof(uint32_t), st));
         if (max_passes > 1) HIP_TRY(hipMemsetAsync(sc.prog.p, 0, need_prog * sizeof(uint32_t), st));
         HIP_TRY(launch_lane(mode, rows_per_lane, (int)block_map.size(), p, st));
@@ -354,8 +351,6 @@ struct SearchRun {
     bool lane_room = false, many_short = false, alternate = false;
     std::vector<uint8_t> use_sp;            // queries that run through the score-profile kernel (option "sp_threshold")
     std::vector<size_t> qcode_off;          // ... and where their padded residue codes start in d_qcodes
-    int bulk_k = 2;                         // streams the multi-pass queries' launches take turns on (alternate)
-    bool tall = false;                      // the batch is ONE group-resident launch of tall workgroups beside the tail kernels (plan_queries)
     uint32_t longest_cols = 0;
     std::vector<QueryPlan> qps;
     std::vector<uint8_t> rotated;                            // one-pass queries that run whole (no tail kernel) on three streams in rotation
@@ -439,7 +434,7 @@ int SearchRun::plan_for(size_t ri, int T, int W, bool resident, bool whole_db, D
 
 int SearchRun::plan_of(size_t ri, uint32_t q, DbPlan **out)
 {
-    return plan_for(ri, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, rotated[q] != 0 || use_sp[q] != 0 || (qps[q].resident && !tall), out);
+    return plan_for(ri, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, rotated[q] != 0 || use_sp[q] != 0 || qps[q].resident, out);
 }
 
 // Which short queries share workgroups.  Candidates: the one-pass queries of up to 72 rows that run without a tail kernel
@@ -554,7 +549,7 @@ int SearchRun::layout_ranges()
         // long chains start with the second chunk, 4 ms in, and the last range is still one of short sequences.
         std::vector<size_t> chunk_order;
         for (size_t i = 0; i < nc; ++i) chunk_order.push_back(descending ? nc - 1 - i : i);
-        const bool short_first = descending && nc >= 3 && c->opt_upload_head && qn <= 4;
+        const bool short_first = descending && nc >= 3 && qn <= 4;
         if (short_first) { chunk_order.insert(chunk_order.begin(), chunk_order.back()); chunk_order.pop_back(); }
         size_t n_part_ev = 0;
         for (size_t i = 0; i < nc; ++i) {
@@ -637,7 +632,7 @@ int SearchRun::plan_queries()
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
     // query's end are zero, like the reference's dummy row 23
     // (binary16 first tier: results below f16_exact_below(extend) are exact -- the pipeline kernel's column offsets take up to 127 of the
-    // 2048; with an extend penalty beyond 300 the tier would be exact below 1 100 only, and the int16 tier is the first)
+    // 2048; with an extend penalty beyond 237 the tier would be exact below 1 100 only, and the int16 tier is the first)
     main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 && f16_exact_below(c->extend_gap) >= 1100 ? Mode::F16 : Mode::PK16);
     f16_thr = f16_exact_below(c->extend_gap);
     // a database with a long-sequence tail is searched with launch shapes that leave room for lane-systolic waves
@@ -650,7 +645,6 @@ int SearchRun::plan_queries()
         ensure_cuts(c);
         for (size_t g = 0; g < c->cut_lane.size() && !lane_room; ++g) lane_room = c->cut_lane[g] < 64;
     }
-    if (c->opt_lane_room >= 0) lane_room = c->opt_lane_room != 0 && main_mode != Mode::I32;
     if (dbg) fprintf(stderr, "swimm_hip: ranges laid out, uploader started %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     qps.assign(qn, QueryPlan{});
     rotated.assign(qn, 0);
@@ -663,7 +657,7 @@ int SearchRun::plan_queries()
     // with an extreme sequence -- c3's 35 000 residues are 6x a CU's mean load -- keeps the tail kernel, whose chain
     // is 3.6x faster per column than a 4-wave workgroup's)
     many_short = n_short >= 8 && !streaming;
-    const bool rotate = many_short && c->opt_rotate && (double)longest_cols <= 2.0 * (double)c->total_cols / c->num_cu;
+    const bool rotate = many_short && (double)longest_cols <= 2.0 * (double)c->total_cols / c->num_cu;
     prof_elems = 0;
     // Group-resident batch launches (option "resident"): ONE launch per launch shape whose items are (group, query) pairs.
     // The batch gets the 4-wave shape that wastes the fewest padded rows at that shape's rate (a query of its own shape
@@ -751,43 +745,7 @@ int SearchRun::plan_queries()
     c->batch_now = batch_formed;
     if (build_stacks()) return 1;
     c->batch_now = false;
-    // A database that is small beside the chip AND has sequences that are long beside a CU's share (Swiss-Prot's shape at a
-    // tenth of its size: 423 groups for 256 CUs, the longest bulk group 4x a CU's mean load): the 4-wave batch above was
-    // rejected because its longest item -- a group through all 43 passes of the longest query at 1.2 us per column-pass, three
-    // workgroups sharing the CU -- would outlast the search, and one launch per pass is bound by the longest group's chain
-    // in EVERY pass while most workgroups idle (c3 at 10 %: 232 ms for 97 ms of work).  Then: ONE group-resident launch
-    // of TALL workgroups -- 12 waves x 24 rows, one workgroup per CU -- whose items are (group, query) pairs: the chain of the
-    // longest item is 20 passes at 0.6 us per column-pass, every CU has an item at all times, and the shape leaves a
-    // lane-systolic wave its 80 registers, so the long-sequence tail runs beside it (all queries' chains in one launch).
-    tall = false;
-    if (!batch_formed && c->opt_tall != 0 && c->opt_dynamic && !streaming && qn >= 2 && main_mode == Mode::F16 && !c->opt_T && !c->opt_W && !c->opt_maxW &&
-        c->opt_resident != 0 && !((uint64_t)qn * S > 0xFFFFFFFFull || prof_elems_bound(qm, qn) > 0xFFFFFFFFull)) {
-        const int T = 24, W = 12;
-        double est_pp = 0, rows_tall = 0;
-        uint32_t n_multi_pp = 0, max_p = 1;
-        for (uint32_t q = 0; q < qn; ++q) {
-            QueryPlan t{};
-            if (choose_plan(c, main_mode, qm[q], lane_room, false, &t)) return 1;
-            est_pp += t.est_s; n_multi_pp += t.passes > 1;
-            const uint32_t ps = (qm[q] + T * W - 1) / (T * W);
-            rows_tall += (double)ps * T * W; max_p = std::max(max_p, ps);
-        }
-        if (n_multi_pp >= 2 && c->opt_alternate) est_pp /= 1.6;          // (two streams: the chains of two queries' passes overlap)
-        plan_imbalance(c, c->num_cu);                                     // (builds the list of bulk groups)
-        const double longest_bulk = c->bulk.cols.empty() ? 0.0 : (double)c->bulk.cols[0];
-        const double est_tall = std::max(rows_tall * (double)c->total_cols * kGroupSeqs / (0.91 * shape_gcups(T, W) * 1e9), longest_bulk * max_p * 0.6e-6) * 1.05;
-        tall = c->opt_tall == 1 || est_tall < 0.85 * est_pp;
-        if (dbg) fprintf(stderr, "swimm_hip: launches per pass estimated at %.1f ms, one launch of 12 x 24-row workgroups at %.1f ms: %s\n", est_pp * 1e3, est_tall * 1e3, tall ? "tall batch" : "per pass");
-        if (tall)
-            for (uint32_t q = 0; q < qn; ++q) {
-                if (rotated[q] || stack_of[q] >= 0 || use_sp[q]) continue;
-                in_batch[q] = 1;
-                qps[q].T = T; qps[q].W = W;
-                qps[q].passes = (int)((qm[q] + T * W - 1) / (T * W));
-                qps[q].mpad = (uint32_t)(qps[q].passes * T * W);
-            }
-    }
-    const bool any_batch = batch_formed || tall;
+    const bool any_batch = batch_formed;
     std::vector<BulkCols> rbulk;
     if (streaming && !batch_formed && ranges.size() > 1) {
         rqps.assign(ranges.size(), std::vector<QueryPlan>(qn));
@@ -831,21 +789,7 @@ int SearchRun::plan_queries()
     // the other query.  (Within ONE such query the even/odd split of run_passes does the same.)
     uint32_t n_multi = 0;
     for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && !in_batch[q] && !use_sp[q] && qps[q].passes > 1;
-    alternate = n_multi >= 2 && c->opt_alternate && !streaming;
-    // ... and on more than two when every launch is bound by its longest group's chain (a database that is small beside the
-    // chip: c3 at a tenth of its size, 423 groups for 256 workgroups, makespan 4x the mean load): the launches of up to four
-    // queries side by side fill the CUs that the one before leaves idle while its last chains run out.
-    bulk_k = 2;
-    if (alternate) {
-        int per_cu = 1;
-        if (wgs_per_cu(c, main_mode, qps[qn - 1].T, qps[qn - 1].W, false, &per_cu)) return 1;
-        const double imb = plan_imbalance(c, n_workgroups(c, per_cu));
-        // (measured, profiles/r03_c3_scales.txt: three and four streams LOSE -- c3 at 10 % 5 880 -> 4 830 / 5 490 GCUPS, at 30 % 7 560 -> 7 190 /
-        // 7 360 -- the further streams share hardware queues with the ones in use; the option stays for A/B runs)
-        bulk_k = c->opt_bulk_streams > 0 ? c->opt_bulk_streams : 2;
-        bulk_k = (int)std::min<uint32_t>((uint32_t)bulk_k, n_multi);
-        if (dbg) fprintf(stderr, "swimm_hip: makespan / mean load of the bulk groups %.2f: the queries' passes take turns on %d streams\n", imb, bulk_k);
-    }
+    alternate = n_multi >= 2 && !streaming;
     c->batch_now = any_batch;
     return 0;
 }
@@ -985,13 +929,7 @@ int SearchRun::size_buffers()
         if (dbg) fprintf(stderr, "swimm_hip: buffer sizes known %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
         HIP_TRY(c->d_bnd.reserve(need_bnd));
         if (alternate || c->batch_now || streaming) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
-        if ((c->batch_now && streaming) || (alternate && bulk_k > 2)) HIP_TRY(c->d_bnd_c.reserve(need_bnd));
-        if (alternate && bulk_k > 3) HIP_TRY(c->d_bnd_d.reserve(need_bnd));
-        for (int i = 0; i < 2 && alternate && i + 2 < bulk_k; ++i)
-            if (!c->stream_t[i]) {
-                HIP_TRY(hipStreamCreate(&c->stream_t[i]));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_tail_t[i], hipEventDisableTiming));
-            }
+        if (c->batch_now && streaming) HIP_TRY(c->d_bnd_c.reserve(need_bnd));
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
@@ -1028,10 +966,9 @@ int SearchRun::issue()
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(hipEventRecord(c->ev_ready, c->stream));          // profiles uploaded, scores zeroed
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_ready, 0));
-    for (int i = 0; i < 2; ++i) if (c->stream_t[i]) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], c->ev_ready, 0));
     HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_ready, 0));
     uint32_t one_pass_seen = 0;
-    double alt_rows[4] = {0, 0, 0, 0};
+    double alt_rows[2] = {0, 0};
     HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_ready, 0));
     while (c->ev_query.size() < 2 * (size_t)qn) {
         hipEvent_t e;
@@ -1089,7 +1026,6 @@ int SearchRun::issue()
             HIP_TRY(hipStreamWaitEvent(c->stream, last.ready, 0));
             HIP_TRY(hipStreamWaitEvent(c->stream_b, last.ready, 0));
             HIP_TRY(hipStreamWaitEvent(c->stream2, last.ready, 0));
-            for (int i = 0; i < 2; ++i) if (c->stream_t[i]) HIP_TRY(hipStreamWaitEvent(c->stream_t[i], last.ready, 0));
         }
         // The long-sequence tail of this range first (a few long serial chains, one wave each, beside the bulk kernels: 3 bulk
         // waves of 144 VGPRs + 1 lane wave of 80 fill a SIMD's 512 registers exactly): every query that has one joins ONE
@@ -1100,7 +1036,7 @@ int SearchRun::issue()
             const LaneList *ll = nullptr;
             for (uint32_t k = 0; k < qn; ++k) {
                 const uint32_t q = qn - 1 - k;
-                if (stack_of[q] >= 0 || (qps[q].resident && !tall) || rotated[q] || use_sp[q]) continue;      // (every group through the pipeline kernel)
+                if (stack_of[q] >= 0 || qps[q].resident || rotated[q] || use_sp[q]) continue;      // (every group through the pipeline kernel)
                 DbPlan *dp = nullptr;
                 if (plan_of(ri, q, &dp)) return 1;
                 if (dp->tail.n == 0) continue;
@@ -1164,12 +1100,9 @@ int SearchRun::issue()
             // Each query goes to the stream with less work so far (padded rows), longest first: strict turns left one stream
             // 6 % more rows on c3 and the other idle for the last 60 ms.
             if (alternate && !rotated[q] && !qps[q].resident && !(many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows)) {
-                int pick = 0;
-                for (int k = 1; k < bulk_k; ++k) if (alt_rows[k] < alt_rows[pick]) pick = k;
+                const int pick = alt_rows[1] < alt_rows[0] ? 1 : 0;
                 alt_rows[pick] += (double)qps[q].passes * qps[q].W * qps[q].T;
                 if (pick == 1) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
-                else if (pick == 2) { bulk_stream = c->stream_t[0]; bnd = &c->d_bnd_c; }
-                else if (pick == 3) { bulk_stream = c->stream_t[1]; bnd = &c->d_bnd_d; }
             }
             if (streaming && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
             if (dbg)
@@ -1210,7 +1143,7 @@ int SearchRun::issue()
                 const int T = kv.first.first, W = kv.first.second;
                 const uint32_t nqb = (uint32_t)kv.second.size();
                 DbPlan *dp = nullptr;
-                if (plan_for(ri, T, W, true, !tall, &dp)) return 1;
+                if (plan_for(ri, T, W, true, true, &dp)) return 1;
                 uint64_t pass_sum = 0;
                 uint32_t max_p = 1;
                 for (const Unit &u : kv.second) {
@@ -1242,7 +1175,7 @@ int SearchRun::issue()
                         for (uint32_t q : stacks[u.stack].q) { HIP_TRY(hipEventRecord(c->ev_query[2 * q], st)); HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], st)); }
                     } else {
                         HIP_TRY(hipEventRecord(c->ev_query[2 * u.q], st));
-                        if (!tall || dp->tail.n == 0) HIP_TRY(hipEventRecord(c->ev_query[2 * u.q + 1], st));      // (a tall batch's members have their tail launch's event)
+                        HIP_TRY(hipEventRecord(c->ev_query[2 * u.q + 1], st));
                     }
                 }
                 ++bi;
@@ -1262,14 +1195,6 @@ int SearchRun::issue()
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_b, 0));
         HIP_TRY(hipEventRecord(c->ev_a, c->stream2));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_a, 0));
-        // (a chain-bound search rotates its tail launches over further streams, range after range: a query's tail kernel
-        // of an EARLY range may sit on one of them while ev_query[2q + 1] only marks the last range's -- the promotion
-        // ladder must not scan a score row a lane kernel is still writing)
-        for (int i = 0; i < 2; ++i) {
-            if (!c->stream_t[i]) continue;
-            HIP_TRY(hipEventRecord(c->ev_tail_t[i], c->stream_t[i]));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail_t[i], 0));
-        }
         for (uint32_t q = 0; q < qn; ++q) HIP_TRY(hipEventRecord(c->ev_query[2 * q], c->stream));
         c->up->finish(false);
         if (sync_lengths(c)) return 1;             // the promotion re-runs stop every alignment at its true length
@@ -1427,11 +1352,6 @@ int SearchRun::drain()
 {
     HIP_TRY(hipEventRecord(c->ev_tail, c->stream2));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail, 0));
-    for (int i = 0; i < 2; ++i) {
-        if (!c->stream_t[i]) continue;
-        HIP_TRY(hipEventRecord(c->ev_tail_t[i], c->stream_t[i]));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail_t[i], 0));
-    }
     HIP_TRY(hipEventRecord(c->ev_b, c->stream_b));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_b, 0));
     HIP_TRY(hipEventRecord(c->ev_tail3, c->stream3));

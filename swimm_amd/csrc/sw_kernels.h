@@ -69,8 +69,6 @@ struct PipeParams {
     uint32_t n_queries;         // (qdesc != nullptr selects the group-resident kernel: every workgroup takes a group through all
                                 // the passes of an item's query back to back)
     uint32_t bnd_wg_cols;       // group-resident launches: bnd holds this many columns per workgroup, touched by it alone
-    uint32_t n_groups;          // group-resident launches, query-major item order (> 0): item id = query rank * n_groups + group rank -- a workgroup
-                                // takes consecutive groups of ONE query, so its profile strip stays staged from item to item; 0 = group-major
     const uint32_t *wave_out;   // stacks of short queries: per (stack, wave) the score row of the wave's member (group-resident launches: indexed
                                 // through QDesc::wave_tab; a per-pass launch: non-null selects the stack below)
     uint32_t seam_mask;         // per-pass launch of ONE stack: its seam bits ...
@@ -129,7 +127,6 @@ struct LaneParams {
     int32_t *out;
     int goe, ge;
     uint32_t *err;              // watchdog word
-    int agent_acquire;          // 1: consumers of chained passes issue an agent-scope acquire after every poll (A/B option)
 };
 size_t lane_lds_bytes(int rows_per_lane);
 // rows_per_lane: kLaneRows (any query), or 4 / 2 for a one-pass launch of a query of <= 256 / <= 128 rows

@@ -282,7 +282,7 @@ __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *q) { return
                         next_it = it + 1 < it_end ? it + 1 : kNoItem; \
                     } \
                     if (next_it != kNoItem) { \
-                        const Item niv = load_item(p.items, RES ? (qmajor ? next_it % p.n_groups : next_it / nq) : next_it); \
+                        const Item niv = load_item(p.items, RES ? next_it / nq : next_it); \
                         ndb = niv.db; ncc = 0; nhalf = niv.half; \
                     } else { \
                         have_next = false; \
@@ -449,7 +449,6 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
         pf_win = win;
     };
     const uint32_t nq = RES ? p.n_queries : 1u;
-    const bool qmajor = RES && p.n_groups != 0;
     uint64_t bnd_off = 0;
     const uint8_t *dbp = nullptr;
     uint32_t nwa = 0, nwb = 0;     // residues of the wave's next chunk, loaded one step ahead
@@ -483,13 +482,13 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             if (cc == 0) {                        // first chunk of a new item (RES: item-pass): reset the DP state
                 // the item is the same for the whole wave: one scalar load, descriptor in scalar registers
                 const uint32_t vi = __builtin_amdgcn_readfirstlane(it);
-                const uint32_t gi = RES ? (qmajor ? vi % p.n_groups : vi / nq) : vi;
+                const uint32_t gi = RES ? vi / nq : vi;
                 const Item iv = load_item(p.items, gi);
                 nch = iv.ncols / C; dbp = iv.db; seq0 = iv.seq0;
                 half = iv.half;
                 bnd_off = RES ? (uint64_t)blockIdx.x * p.bnd_wg_cols : iv.bnd_off;
                 if (RES && pass == 0) {               // a new (group, query) item: the query's parameters, one scalar load
-                    cur_q = nq - 1 - (qmajor ? vi / p.n_groups : vi - gi * nq);
+                    cur_q = nq - 1 - (vi - gi * nq);
                     const QDesc qd = load_qdesc(p.qdesc, cur_q);
                     passes = qd.passes; q_prof = p.prof + qd.prof_off; q_stride = qd.prof_stride; q_out = p.out + qd.out_off;
                     seam = false;
@@ -733,7 +732,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                 } else {
                     const uint32_t nv = DYN ? __builtin_amdgcn_readfirstlane(seq[(n + 1) & (kSeqRing - 1)]) : (it + 1 < it_end ? it + 1 : kNoItem);
                     if (nv != kNoItem) {
-                        const uint32_t nqi = nq - 1 - (qmajor ? nv / p.n_groups : nv - (nv / nq) * nq);
+                        const uint32_t nqi = nq - 1 - (nv - (nv / nq) * nq);
                         const int nwin = (int)(nqi << 16);
                         if (nwin != staged_win) {
                             const QDesc nqd = load_qdesc(p.qdesc, nqi);
@@ -1105,11 +1104,10 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
                     if (dead) { if (lane == 0) atomicOr(p.err, 4u); feeding = false; return false; }
                     // The boundary values below are read with agent-scope atomic loads (sc1: they bypass this CU's L1
                     // and are served by memory the producer's sc1 stores went through to), so nothing stale can be
-                    // hit and the fence only has to keep the compiler from moving those loads above the poll.
-                    // p.agent_acquire = 1 makes it a full agent-scope acquire (buffer_inv sc1) instead: the
-                    // by-the-book form, measured at no gain in safety and a CU-wide L1 invalidate per poll.
-                    if (p.agent_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // hit and the fence only has to keep the compiler from moving those loads above the poll.  (A full
+                    // agent-scope acquire -- buffer_inv sc1 -- after every poll was measured in round 2: it adds nothing the
+                    // sc1 loads do not give and costs 3.7 % on c3, profiles/NOTES.md.)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
                 {   // lane jj fetches column jj (the lanes above repeat the last column: same cache line, nothing extra)
                     const unsigned long long v = __hip_atomic_load(bnd_in + (size_t)f.col0 + (lane < C ? lane : C - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -97,7 +97,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     swimm_hip_clear_db(c);
     pool_trim(c);
     for (hipEvent_t e : c->part_ev) (void)hipEventDestroy(e);
-    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_bnd_d.release(); c->d_qcodes.release(); c->d_sub16.release(); c->d_qdesc.release(); c->d_wave_out.release();
+    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_qcodes.release(); c->d_sub16.release(); c->d_qdesc.release(); c->d_wave_out.release();
     if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = c->pin_used = 0; }
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_t[0].release(); c->tail_scratch_t[1].release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release(); c->d_ladder_counts.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -111,10 +111,6 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     for (hipEvent_t e : c->ev_query) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->launch_ev) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    for (int i = 0; i < 2; ++i) {
-        if (c->stream_t[i]) (void)hipStreamDestroy(c->stream_t[i]);
-        if (c->ev_tail_t[i]) (void)hipEventDestroy(c->ev_tail_t[i]);
-    }
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
     if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);
@@ -482,39 +478,20 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
         if (value < 0 || value > 1000) return fail("tail_cap must be 0..1000 (per mille of the cells; 0 = no cap)");
         c->opt_tail_cap = value;
         release_plans(c);
-    } else if (!strcmp(key, "rotate")) {
-        c->opt_rotate = value != 0;
-    } else if (!strcmp(key, "batch_order")) {
-        c->opt_batch_order = value != 0;
     } else if (!strcmp(key, "sp_threshold")) {
         if (value < 0 || value > 65536) return fail("sp_threshold must be 0 (every query through the score-profile kernel) .. 65536 (none)");
         c->opt_sp_threshold = value;
-    } else if (!strcmp(key, "bulk_streams")) {
-        if (value < 0 || value > 4) return fail("bulk_streams must be 0 (auto) .. 4");
-        c->opt_bulk_streams = value;
     } else if (!strcmp(key, "cut")) {
         if (value < 0 || value > 1000) return fail("cut must be 0 (never) .. 1000 (tenths: cost of a lane-systolic cell against a padded pipeline cell)");
         c->opt_cut = value;
         release_plans(c);
-    } else if (!strcmp(key, "tall")) {
-        if (value < -1 || value > 1) return fail("tall must be -1 (auto), 0 or 1");
-        c->opt_tall = value;
     } else if (!strcmp(key, "stack")) {
         c->opt_stack = value != 0;
-    } else if (!strcmp(key, "lane_rows")) {
-        c->opt_lane_rows = value != 0;
-    } else if (!strcmp(key, "lane_room")) {
-        if (value < -1 || value > 1) return fail("lane_room must be -1 (auto), 0 or 1");
-        c->opt_lane_room = value;
     } else if (!strcmp(key, "resident")) {
         if (value < -1 || value > 1) return fail("resident must be -1 (auto), 0 or 1");
         c->opt_resident = value;
     } else if (!strcmp(key, "time_launches")) {
         c->opt_time_launches = value != 0;
-    } else if (!strcmp(key, "alternate")) {
-        c->opt_alternate = value != 0;
-    } else if (!strcmp(key, "split")) {
-        c->opt_split = value != 0;
     } else if (!strcmp(key, "dynamic")) {
         c->opt_dynamic = value != 0;
     } else if (!strcmp(key, "f16")) {
@@ -526,20 +503,12 @@ int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value)
     } else if (!strcmp(key, "lazy_upload")) {
         c->opt_lazy_upload = value != 0;
         if (c->opt_lazy_upload && ensure_uploader(c)) return 1;      // (the uploader thread starts -- and warms up -- now, not inside the first search)
-    } else if (!strcmp(key, "upload_head")) {
-        c->opt_upload_head = value != 0;
     } else if (!strcmp(key, "upload_piece_kib")) {
         if (value < 16) return fail("upload_piece_kib must be >= 16");
         c->opt_upload_piece_kib = value;
-    } else if (!strcmp(key, "lane_acquire")) {
-        c->opt_lane_acquire = value != 0;
     } else if (!strcmp(key, "wg_limit")) {
         if (value < 0) return fail("wg_limit must be >= 0 (0 = as many workgroups as the chip holds)");
         c->opt_wg_limit = value;
-        release_plans(c);
-    } else if (!strcmp(key, "wgs_per_cu")) {
-        if (value < 0 || value > 16) return fail("wgs_per_cu must be 0..16");
-        c->opt_wgs_per_cu = value;
         release_plans(c);
     } else {
         return fail("swimm_hip_set_option: unknown key '%s'", key);

@@ -179,7 +179,6 @@ struct swimm_hip_ctx {
     hipEvent_t ev_copied = nullptr;
     DevBuf<uint8_t> up_b; DevBuf<uint16_t> up_n; DevBuf<uint32_t> up_disp, up_gcols, up_off; DevBuf<uint64_t> up_goff;   // upload scratch, reused chunk after chunk
     int opt_upload_piece_kib = 98304;   // lazy_upload: chunks and slabs larger than this are recorded in pieces of about this size (96 MiB, the reference's chunk size)
-    int opt_upload_head = 1;            // lazy_upload, up to four queries: the chunk with the shortest sequences travels first, in parts of 16 MiB, 32 MiB and the rest (0: the database in descending order, whole chunks)
     int opt_lazy_upload = 0;            // 1: add_chunk / add_sequences record the caller's buffers, the first search streams them in
     hipStream_t stream3 = nullptr;      // promotion re-runs
     hipEvent_t ev_ready = nullptr, ev_tail3 = nullptr;
@@ -187,41 +186,33 @@ struct swimm_hip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cu = 0;
     // options (swimm_hip_set_option)
-    int opt_T = 0, opt_maxW = 0, opt_W = 0, opt_wgs_per_cu = 0;   // launch shape: 0 = chosen per query
+    int opt_T = 0, opt_maxW = 0, opt_W = 0;   // launch shape: 0 = chosen per query
     int opt_force_i32 = 0;              // 1: everything in int32
     int opt_f16 = 1;                    // 1: packed binary16 first tier (exact below 2048, then int16, then int32)
     int opt_tail_mode = 0;              // 0 auto, 1 every group through the lane kernel, 2 none
     int opt_tail_frac = 30;             // a group goes to the lane kernel when it is longer than this percentage of a CU's mean load ...
     int opt_tail_cap = 25;              // ... as long as the tail stays below this many per mille of the search's cells (0 = no cap)
     int opt_dynamic = 1;                // 1: workgroups pull items from a global queue (default); 0: static partition by the host
-    int opt_lane_rows = 1;              // 1: one-pass lane launches of short queries use 2 / 4 rows per lane instead of 8
     int opt_resident = -1;              // group-resident batch launches: -1 = when the batch has two or more queries that are not rotated, 0 never, 1 always
-    int opt_lane_room = -1;             // launch shapes must leave a lane-systolic wave its registers: -1 = when the database has a long-sequence tail, 0 never, 1 always
     bool batch_now = false;             // the search in progress runs its non-rotated queries as group-resident batch launches
     std::vector<uint8_t> stream_tail;   // streaming search: the tail flags of the whole database (pick_tail)
     bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
     DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
     DevBuf<uint32_t> d_wave_out;        // stacks of short queries: per (stack, wave) the first element of the wave's member's score row
-    int opt_tall = 0;                   // group-resident batches of TALL workgroups (12 x 24 rows, one per CU) beside the tail kernels for a database whose per-pass launches would be chain-bound: 0 = never (default: measured slower than launches per pass beside ONE lane-systolic launch for all queries, c3 at 10 % 4 990 vs 6 000 GCUPS), -1 = by estimate, 1 = whenever the 4-wave batch is not formed
     int opt_cut = 35;                   // outlier pairs: a group's longest pairs leave it for the lane-systolic kernel when that saves the pipeline kernel more padded cells than opt_cut/10 x the pairs' own (0 = never)
     std::vector<uint32_t> cut_cols;     // per group: the columns the pipeline kernel aligns (<= ncols; the pairs that are longer are lane-systolic items as well)
     std::vector<uint8_t> cut_lane;      // per group: the first lane (pair) that is an outlier (64 = none)
     int opt_sp_threshold = 65536;       // queries of at least this many rows use the score-profile kernel (the reference's query_length_threshold, MICsearch.c:39-43); 65536 = none
     DevBuf<int8_t> d_qcodes;            // score-profile kernel: the residue codes of its queries, each padded with the dummy code to a multiple of 32
     DevBuf<uint16_t> d_sub16;           // ... and the substitution matrix as binary16 bits [24][32]
-    int opt_batch_order = 0;            // group-resident batches of one-pass queries: 1 = query-major item order (a workgroup stays with a query), 0 = group-major (default; measured equal)
     int opt_stack = 1;                  // 1: short one-pass queries of a batch share workgroups (several queries stacked along the strips)
     int opt_time_launches = 0;          // 1: every pipeline launch is bracketed by events on its own stream (measurement aid, bench.py)
     std::vector<hipEvent_t> launch_ev;  // pairs (before, after), grown on demand
     size_t launch_ev_used = 0;
     double launch_ms_sum = 0;           // sum of the pipeline launches' own durations in the last search
     uint32_t launch_ms_n = 0;
-    int opt_rotate = 1;                 // 1: eight or more one-pass queries run whole on three streams in rotation; 0: they join the group-resident batch
-    int opt_alternate = 1;              // 1: the passes of consecutive multi-pass queries alternate between two streams
-    int opt_split = 1;                  // 1: multi-pass queries run the even- and odd-ranked groups as two kernels on two streams
     int opt_bnd_mib = 16384;            // HBM budget of the pass-boundary buffer (MiB)
     int opt_score_mib = 32768;          // HBM budget of the score rows of one query batch (MiB)
-    int opt_lane_acquire = 0;           // 1: chained lane passes take an agent-scope acquire after every progress poll (default: sc1 loads only)
     int opt_wg_limit = 0;               // > 0: at most this many persistent workgroups per pipeline launch (tests: long per-workgroup item sequences on a small database)
     // caches that depend on the resident database / the code objects
     BulkCols bulk;                      // the resident database's bulk groups (built on demand) and their makespan factors
@@ -248,8 +239,6 @@ struct swimm_hip_ctx {
     DevBuf<int16_t> d_prof;
     DevBuf<uint2> d_bnd, d_bnd_b;       // pass-boundary rows; the second one for the queries whose passes run on stream_b
     DevBuf<uint2> d_bnd_c;              // ... and a third for the group-resident launches of a database that streams in (three ranges in flight)
-    DevBuf<uint2> d_bnd_d;              // ... and a fourth: chain-bound searches run the passes of up to four queries side by side
-    int opt_bulk_streams = 0;           // streams the passes of consecutive multi-pass queries take turns on: 0 = by the work lists' imbalance (2..4), else 1..4
     Uploader *up = nullptr;             // the thread that copies a lazily uploaded database (created with the first recorded chunk)
     void *pin = nullptr;                // pinned arena the work lists travel through (list_copy)
     size_t pin_cap = 0, pin_used = 0;
@@ -261,10 +250,7 @@ struct swimm_hip_ctx {
     std::vector<std::pair<void *, size_t>> pool;   // device buffers of a cleared database, kept for the chunks registered next (freed by the next search)
     DevBuf<unsigned long long> d_stamps;   // diagnostic build only
     LaneScratch tail_scratch;           // lane kernel on stream 2 (long-sequence tail: the launch of the queries with 8 rows per lane)
-    // the tail launches of the short queries (4 and 2 rows per lane) run beside it: two more streams (created on first use), scratch and events
-    hipStream_t stream_t[2] = {nullptr, nullptr};
-    hipEvent_t ev_tail_t[2] = {nullptr, nullptr};
-    LaneScratch tail_scratch_t[2];
+    LaneScratch tail_scratch_t[2];      // ... and the launches of the short queries (4 and 2 rows per lane), same stream
     LaneScratch rerun_scratch;          // lane kernel on stream 3 (promotion re-runs)
     DevBuf<LaneItem> d_rerun_items;
     DevBuf<uint32_t> d_satlist;

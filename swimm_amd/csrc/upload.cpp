@@ -25,7 +25,13 @@ int pool_alloc(swimm_hip_ctx *c, size_t bytes, void **out, size_t *cap)
         c->pool.erase(c->pool.begin() + best);
         return 0;
     }
-    HIP_TRY(hipMalloc(out, bytes));
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory && !c->pool.empty()) {      // the pool still holds what the old database left: hand it back and try again
+        (void)hipGetLastError();
+        pool_trim(c);
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) return fail("hipMalloc of %zu bytes for a database chunk: %s", bytes, hipGetErrorString(e));
     *cap = bytes;
     return 0;
 }

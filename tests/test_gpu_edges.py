@@ -229,7 +229,7 @@ def test_outlier_pairs_leave_their_group():
         s[at:at + len(src)] = src
         seqs.append(s)
     seqs += [rnd(rng, int(n)) for n in rng.integers(600, 700, 130)]          # a full group of medium sequences between bulk and outliers
-    for opts in ({}, {"cut": 0}, {"cut": 5}, {"resident": 0}, {"tall": 1}, {"tail_mode": 2}, {"f16": 0}, {"lazy_upload": 1, "upload_piece_kib": 64}):
+    for opts in ({}, {"cut": 0}, {"cut": 5}, {"resident": 0}, {"resident": 1}, {"tail_mode": 2}, {"f16": 0}, {"lazy_upload": 1, "upload_piece_kib": 64}):
         want, stats = run_case(seqs, [q1, q2, q3], matrix="blosum50", opts=opts, max_chunk=300000)
     assert want.max() > 2048
 
@@ -297,7 +297,7 @@ def test_random_small_cases():
         if rng.random() < 0.2:
             opts["dynamic"] = 0
         if rng.random() < 0.2:
-            opts["split"] = 0
+            opts["bnd_mib"] = 1
         if rng.random() < 0.1:
             opts = {"force_i32": 1}
         try:

@@ -45,9 +45,9 @@ def draw_case(seed):
     go, ge = int(rng.integers(0, 21)), int(rng.integers(0, int(os.environ.get("SWIMM_FUZZ_GE_MAX", "6"))))     # (the binary16 tier's offset period depends on ge)
     opts = {}
     pool = [("resident", [0, 1]), ("dynamic", [0]), ("tail_mode", [1, 2]), ("f16", [0]), ("force_i32", [1]), ("wg_limit", [4, 64]),
-            ("bnd_mib", [1]), ("alternate", [0]), ("split", [0]), ("rotate", [0]), ("lane_rows", [0]), ("score_mib", [1]), ("tail_frac", [10, 200]),
-            ("lane_room", [0, 1]), ("lane_acquire", [1]), ("max_waves", [1, 4, 8]), ("upload_piece_kib", [16, 64, 1024]), ("tail_cap", [0, 5, 80]),
-            ("sp_threshold", [0, 64, 500]), ("stack", [0]), ("cut", [0, 5, 200]), ("tall", [1]), ("bulk_streams", [1, 3, 4]), ("upload_head", [0]), ("batch_order", [1])]
+            ("bnd_mib", [1]), ("score_mib", [1]), ("tail_frac", [10, 200]),
+            ("max_waves", [1, 4, 8]), ("upload_piece_kib", [16, 64, 1024]), ("tail_cap", [0, 5, 80]),
+            ("sp_threshold", [0, 64, 500]), ("stack", [0]), ("cut", [0, 5, 200])]
     for key, vals in pool:
         if rng.random() < 0.2:
             opts[key] = int(rng.choice(vals))
@@ -156,8 +156,8 @@ def test_random_session_on_one_context(seed):
                 s.set_queries(a, m, disp, submat.table(mat), go, ge)
             elif what == "option":
                 key, vals = [("resident", [-1, 0, 1]), ("dynamic", [0, 1]), ("tail_mode", [0, 1, 2]), ("f16", [0, 1]), ("wg_limit", [0, 8]),
-                             ("bnd_mib", [1, 16384]), ("alternate", [0, 1]), ("rotate", [0, 1]), ("score_mib", [1, 32768]),
-                             ("sp_threshold", [0, 100, 65536]), ("stack", [0, 1]), ("cut", [0, 35]), ("tall", [0, 1])][int(rng.integers(0, 13))]
+                             ("bnd_mib", [1, 16384]), ("score_mib", [1, 32768]), ("tail_frac", [10, 30]), ("tail_cap", [0, 25]),
+                             ("sp_threshold", [0, 100, 65536]), ("stack", [0, 1]), ("cut", [0, 35]), ("max_waves", [0, 4])][int(rng.integers(0, 13))]
                 s.set_option(key, int(rng.choice(vals)))
                 continue
             if L is None or a is None:
@@ -214,7 +214,7 @@ def test_short_query_batches_share_workgroups(seed):
          "query_residues": int(m.astype(np.int64).sum()), "matrix": "blosum62" if seed % 2 == 0 else str(rng.choice(MATRICES))}
     go, ge = (10, 2) if seed % 2 == 0 else (int(rng.integers(0, 21)), int(rng.integers(0, 6)))
     opts = {}
-    for key, vals in [("resident", [0, 1]), ("rotate", [0]), ("f16", [0]), ("tail_mode", [2]), ("score_mib", [1]), ("wg_limit", [8]), ("force_i32", [1])]:
+    for key, vals in [("resident", [0, 1]), ("f16", [0]), ("tail_mode", [2]), ("score_mib", [1]), ("wg_limit", [8]), ("force_i32", [1])]:
         if rng.random() < 0.2:
             opts[key] = int(rng.choice(vals))
     sm = submat.table(w["matrix"])

@@ -43,7 +43,7 @@ def test_golden_all_cases(searcher, gin, golden):
         assert st["promoted"] > 0, "W x 3200 self hit must go through the int32 tier"
 
 
-@pytest.mark.parametrize("opts", [{"force_i32": 1}, {"rows_per_wave": 16}, {"max_waves": 1}, {"max_waves": 5, "wgs_per_cu": 1},
+@pytest.mark.parametrize("opts", [{"force_i32": 1}, {"rows_per_wave": 16}, {"max_waves": 1}, {"max_waves": 5, "wg_limit": 256},
                                   {"tail_mode": 1}, {"tail_mode": 2}, {"tail_mode": 1, "rows_per_wave": 16}, {"rows_per_wave": 24},
                                   {"f16": 0}, {"f16": 0, "tail_mode": 2}, {"f16": 1, "rows_per_wave": 24, "tail_mode": 2},
                                   {"dynamic": 0}, {"dynamic": 0, "tail_mode": 2, "f16": 0}, {"dynamic": 0, "tail_mode": 2, "max_waves": 3},
@@ -51,16 +51,16 @@ def test_golden_all_cases(searcher, gin, golden):
                                   {"rows_per_wave": 36}, {"rows_per_wave": 36, "waves": 3, "tail_mode": 2}, {"rows_per_wave": 20, "waves": 7},
                                   {"score_mib": 0}, {"score_mib": 0, "tail_mode": 2}, {"resident": 0, "bnd_mib": 1, "tail_mode": 2},
                                   {"resident": 0, "bnd_mib": 1, "tail_mode": 2, "rows_per_wave": 16, "waves": 4}, {"resident": 0, "bnd_mib": 1, "tail_mode": 2, "force_i32": 1},
-                                  {"resident": 0, "split": 0}, {"resident": 0, "split": 0, "tail_mode": 2}, {"tail_mode": 2, "rows_per_wave": 12, "waves": 3},
-                                  # one launch per query and pass (the default for a single query), alternating streams or not
-                                  {"resident": 0}, {"resident": 0, "tail_mode": 2}, {"resident": 0, "alternate": 0}, {"resident": 0, "alternate": 0, "tail_mode": 1},
+                                  {"tail_mode": 2, "rows_per_wave": 12, "waves": 3},
+                                  # one launch per query and pass (the default for a single query)
+                                  {"resident": 0}, {"resident": 0, "tail_mode": 2}, {"resident": 0, "tail_mode": 1},
                                   {"resident": 0, "rows_per_wave": 28, "waves": 8, "tail_mode": 2},
                                   # group-resident passes (one launch per multi-pass query), also with a deep pipeline: most groups
                                   # are then shorter than the pipeline and idle between their passes
                                   {"resident": 1}, {"resident": 1, "tail_mode": 2}, {"resident": 1, "tail_mode": 1},
                                   {"resident": 1, "tail_mode": 2, "rows_per_wave": 8, "waves": 16}, {"resident": 1, "tail_mode": 2, "rows_per_wave": 28, "waves": 8}, {"resident": 1, "tail_mode": 2, "rows_per_wave": 28, "waves": 16},
                                   {"resident": 1, "tail_mode": 2, "rows_per_wave": 36, "waves": 12}, {"resident": 1, "f16": 0, "tail_mode": 2, "rows_per_wave": 16, "waves": 5},
-                                  {"resident": 1, "force_i32": 1, "rows_per_wave": 16, "waves": 3}, {"lane_room": 0}, {"lane_room": 1, "resident": 1}])
+                                  {"resident": 1, "force_i32": 1, "rows_per_wave": 16, "waves": 3}])
 def test_golden_kernel_variants(gin, golden, opts):
     q, pp, chunked = gin
     N = golden["search"]["n_sequences"]

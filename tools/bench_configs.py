@@ -34,7 +34,6 @@ def main():
     ap.add_argument("--check", type=int, default=0)
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--max-waves", type=int, default=0)
-    ap.add_argument("--wgs-per-cu", type=int, default=0)
     ap.add_argument("--per-query", action="store_true")
     ap.add_argument("--only", type=str, default="", help="comma-separated indices into the config's query list")
     ap.add_argument("--opt", action="append", default=[], help="key=value for swimm_hip_set_option (repeatable)")
@@ -49,7 +48,7 @@ def main():
           f"{len(chunks.chunks)} chunks, padded {chunks.vD / residues:.3f}x, built in {time.time() - t0:.1f} s", flush=True)
     sm = submat.table(cfg["matrix"])
     with hip_backend.HipSearcher(0) as s:
-        for k, v in (("rows_per_wave", args.rows_per_wave), ("max_waves", args.max_waves), ("wgs_per_cu", args.wgs_per_cu)):
+        for k, v in (("rows_per_wave", args.rows_per_wave), ("max_waves", args.max_waves)):
             if v:
                 s.set_option(k, v)
         for kv in args.opt:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the SWIMM hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--scale S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--scale S]
 
 What one invocation measures (no --workload given):
 
@@ -10,11 +10,14 @@ What one invocation measures (no --workload given):
               BLOSUM62, gap 10/2, top-20; K timed steps after W warm-up steps.  With N > 1 every rank holds its own
               1M-sequence shard (seed differs per rank): WEAK scaling -- the same per-GPU work at every N, so that the
               N = 1 point of a scaling run is the single-GPU bench line.
-  N = 1       `secondary`: the Env-NR-shaped configurations north_star's target sentence is written about, each with its
-              own parity sample against the reference, kernel name, `roofline` and `cpu_baseline`:
-                c4  the 5 478-residue query (Q9UKN1-shaped) x the 1.3e9-residue Env-NR subsample, BLOSUM62 10/2
+  N = 1       `secondary`: the other BASELINE.json configurations, each with its own parity sample against the reference,
+              kernel name, `roofline`, `cpu_baseline` and first-search-after-a-cold-upload figures:
+                c3  the 20-query set x the Swiss-Prot-shaped database (540 080 sequences, 0.01 % tail to 35 000), BLOSUM50
+                c4  the 5 478-residue query (Q9UKN1-shaped) x the WHOLE Env-NR-shaped database (35.5 M sequences, 7e9
+                    residues), BLOSUM62 10/2 -- the configuration north_star's ">= 10 x 350 GCUPS" sentence is written about
                 c5  the 20-query set x the Env-NR-shaped database at scale 0.25 (1.75e9 residues), PAM250
-              (2 timed steps each after 1 warm-up step).
+              (2 timed steps each after 1 warm-up step); `summary`, the last object of the line, repeats their headline
+              figures in a few hundred bytes (a driver that keeps only the tail of stdout still sees them).
   N > 1       `strong_scaling`: north_star's multi-GPU case, BASELINE.json configs[4] -- ONE Env-NR-shaped database
               (35.5 M sequences / 7e9 residues), 20 queries, PAM250, cut into 8 N slabs of equal padded size that are
               dealt statically to the N ranks (sharding.assign_chunks); per-rank kernel GCUPS and HBM fraction, which
@@ -25,7 +28,8 @@ What one invocation measures (no --workload given):
 A "step" is one complete search of the resident database shard: DP kernels, promotion re-runs, device top-20; with
 N > 1 the ranks' top-20 lists are all-gathered (RCCL; 20 x 16 bytes per query and rank) and merged on the host --
 the path has no other exchange step.  The database is resident in HBM before the timed region (288 GB holds every
-configuration); the first search after a cold upload is reported beside it as `value_incl_h2d`.
+configuration); the first search after a cold upload is reported beside it as `value_incl_h2d` (the very first cold upload of
+the process: what a one-shot `swimm -S search` pays) and `value_incl_h2d_pooled` (a later re-upload, device buffers reused).
 
 N > 1: one process per GPU.  Under torch.distributed.run the environment carries RANK / LOCAL_RANK / WORLD_SIZE;
 invoked plainly (`python bench.py --gpus N`) this process starts the N ranks itself, before it touches the GPU, and
@@ -69,7 +73,7 @@ VALU_PEAK_CLASS = NUM_CU * 4 * SHADER_HZ / 4 / 1e9
 VALU_CLASS_MEASURED = NUM_CU * 4 * SHADER_HZ / 4.40 / 1e9     # that class in isolation, four waves per SIMD (profiles/r01_valu_issue_rates.txt: 4.40 cycles)
 INSTR_PER_ROW, INSTR_PER_COLUMN = 6.5, 8           # model when no PMC profile matches: 6.5 packed-f16 ops per packed row (column-offset form, fused pair score); per-column overhead
 C4_SCALE = 1.3e9 / 6.99e9                          # the 1.3e9-residue Env-NR subsample of SURVEY 8d
-DEFAULT_SCALE = {"c2": 1.0, "c4": C4_SCALE, "c5": 0.25}
+DEFAULT_SCALE = {"c2": 1.0, "c3": 1.0, "c4": 1.0, "c5": 0.25}
 
 
 def build_shard(seed: int, scale: float):
@@ -133,20 +137,43 @@ def oracle_scores(qa_list, lens, codes, sm, threads):
     return sc[:, :len(lens)], wt, kind
 
 
+SAMPLE_BLOCK = 64
+
+
 def sample_check(qa_list, lens, codes_of, sm, threads, gpu_scores_of, budget_s, n_total):
-    """every k-th sequence of a shard through the CPU checker, k chosen so that the CPU work fits ~budget_s.
-    codes_of(i) -> residues of local sequence i; gpu_scores_of(idx) -> [q, len(idx)] GPU scores of those sequences.
-    -> (ok, stride, sampled sequences, sampled residues, cpu seconds, kind)"""
+    """blocks of 64 consecutive sequences, every k-th block of a shard, through the CPU checker; k chosen so that the CPU
+    work fits ~budget_s (the database is length-sorted: evenly spaced blocks see every length class).
+    codes_of(i0, i1) -> residues of the local sequences [i0, i1); gpu_scores_of(idx) -> [q, len(idx)] GPU scores.
+    -> (ok, stride, sampled sequences, sampled residues, cpu seconds, kind, inputs of the checker run)"""
     q_res = sum(len(q) for q in qa_list)
     residues = float(np.asarray(lens, dtype=np.int64).sum())
     est = q_res * residues / (1.0e9 * max(threads, 1))       # the reference runs at about 1 GCUPS per hardware thread
     stride = max(1, int(np.ceil(est / budget_s)))
-    idx = np.arange(0, n_total, stride, dtype=np.int64)
+    if stride == 1:
+        idx = np.arange(n_total, dtype=np.int64)
+        sub_codes = codes_of(0, n_total)
+    else:
+        starts = np.arange(0, n_total, SAMPLE_BLOCK * stride, dtype=np.int64)
+        idx = np.concatenate([np.arange(b, min(b + SAMPLE_BLOCK, n_total), dtype=np.int64) for b in starts])
+        sub_codes = np.concatenate([codes_of(int(b), int(min(b + SAMPLE_BLOCK, n_total))) for b in starts])
     sub_lens = np.asarray(lens)[idx]
-    sub_codes = np.concatenate([codes_of(int(i)) for i in idx]) if stride > 1 else codes_of(None)
     sc, wt, kind = oracle_scores(qa_list, sub_lens, sub_codes, sm, threads)
     ok = bool(np.array_equal(gpu_scores_of(idx), sc))
-    return ok, stride, len(idx), int(sub_lens.astype(np.int64).sum()), wt, kind
+    return ok, stride, len(idx), int(sub_lens.astype(np.int64).sum()), wt, kind, (sub_lens, sub_codes)
+
+
+def product_m0_gcups(qa_list, sub_lens, sub_codes, sm, threads):
+    """the product's own `-m 0` (swimm_cpu_search, libswimm_host.so: what `swimm -m 0` and the host leg of `-m 2` run) on the
+    checker's sample with the checker's thread count -> GCUPS of real cells; None when it disagrees with itself"""
+    real = np.array([len(q) for q in qa_list], dtype=np.int64)
+    mp = real + (real % 2)
+    dp = np.concatenate([[0], np.cumsum(mp)]).astype(np.uint32)
+    a = np.full(int(mp.sum()), 23, dtype=np.int8)
+    for k, q in enumerate(qa_list):
+        a[dp[k]:dp[k] + real[k]] = q
+    one = host.assemble_single_chunk(sub_lens, sub_codes, 32, 60)
+    _, wt = host.cpu_search(a, mp.astype(np.uint16), dp, one["b"], one["n"], one["disp"], sm, 10, 2, 32, threads=threads)
+    return float(real.sum()) * float(np.asarray(sub_lens, dtype=np.int64).sum()) / max(wt, 1e-9) / 1e9
 
 
 def pmc_profiles(workload, scale):
@@ -202,6 +229,7 @@ class Env:
     dist = None; rccl = None; rccl_ranks = 0; rccl_error = None
     share = False; dev_index = 0; physical_gpus = 1
     threads = 1; cores = 1; threads_all = 1
+    cpus = ""; pci = ""          # the CPUs this rank's threads are bound to, the PCI address of its device
 
 
 def setup(args) -> Env:
@@ -218,8 +246,9 @@ def setup(args) -> Env:
     visible = torch.cuda.device_count()
     env.dev_index = 0 if env.share else env.local_rank % max(visible, 1)
     torch.cuda.set_device(env.dev_index)
-    env.threads_all, env.cores = host_cpus()
-    env.threads = max(1, env.threads_all // env.world)
+    env.all_cpus = sorted(os.sched_getaffinity(0))
+    env.pci = hip_backend.device_pci_bus_id(env.dev_index)
+    bdfs = [env.pci]
     if env.world > 1:
         import torch.distributed as dist
         env.dist = dist
@@ -268,7 +297,34 @@ def setup(args) -> Env:
                 env.rccl_error = " | ".join(errs)[:2000]
         else:
             env.rccl_error = "not attempted: all ranks share one device (SWIMM_BENCH_SHARE_DEVICE=1)"
+        bdfs = [None] * env.world
+        dist.all_gather_object(bdfs, env.pci)
+    # Placement: this rank's threads -- the library's uploader thread (copies out of pageable memory), the checker's OpenMP
+    # team, numpy -- on the CPUs local to its GPU, shared by whole cores with the ranks whose GPUs name the same CPUs
+    # (swimm_amd/csrc/host/affinity.h; plain sched_setaffinity, threads started from here on inherit it).  SWIMM_HIP_BIND=0 skips it.
+    if os.environ.get("SWIMM_HIP_BIND") != "0":
+        mine = host.affinity_plan(bdfs, env.rank, env.all_cpus)
+        host.affinity_apply(mine)
+        env.cpus = host._cpulist(mine)
+    env.threads_all, env.cores = host_cpus()
+    env.threads = env.threads_all            # (the bound set IS the rank's share of the host)
     return env
+
+
+class all_host_cpus:
+    """N = 1 only: the CPU baseline is what the WHOLE host can do, not the socket next to the GPU"""
+
+    def __init__(self, env):
+        self.env = env
+
+    def __enter__(self):
+        self.before = sorted(os.sched_getaffinity(0))
+        if self.env.world == 1:
+            os.sched_setaffinity(0, self.env.all_cpus)
+        return host_cpus()
+
+    def __exit__(self, *exc):
+        os.sched_setaffinity(0, self.before)
 
 
 def make_workload(env: Env, name: str, scale: float):
@@ -286,7 +342,7 @@ def make_workload(env: Env, name: str, scale: float):
         w["my_residues"], w["my_padded"] = shard["residues"], chunks.vD
         offs = np.concatenate([[0], np.cumsum(shard["lengths"].astype(np.int64))])
         w["local_index"] = np.arange(shard["n"], dtype=np.int64)      # position of the rank's sequences in its score rows
-        w["codes_of"] = lambda i: shard["codes"] if i is None else shard["codes"][offs[i]:offs[i + 1]]
+        w["codes_of"] = lambda i0, i1: shard["codes"][offs[i0]:offs[i1]]
         w["index_base"] = env.rank * (1 << 40)                         # ranks hold disjoint databases: make the merged indices distinct
         w["text"] = "c2: 375-aa query x 1M synthetic proteins per GPU, BLOSUM62 g10 e2, top-20"
         w["scaling"] = "weak"
@@ -309,11 +365,25 @@ def make_workload(env: Env, name: str, scale: float):
         w["my_lens"] = db.lengths[local_index]
         w["my_n"], w["n_valid"], w["score_stride"] = len(local_index), db.n, (db.n + 127) // 128 * 128
         w["my_residues"], w["my_padded"] = int(w["my_lens"].astype(np.int64).sum()), sum(s[2] for s in mine)
-        w["codes_of"] = lambda i: np.concatenate(slab_codes) if i is None else db.codes(int(local_index[i]), int(local_index[i]) + 1)
+        slab_first = np.concatenate([[0], np.cumsum([s1 - s0 for s0, s1, _ in mine])]).astype(np.int64)       # local index of every slab's first sequence
+
+        def codes_of(i0, i1):
+            """residues of the rank's local sequences [i0, i1), out of the slabs it holds in memory"""
+            out = []
+            for k, (s0, s1, _) in enumerate(mine):
+                a0, a1 = max(i0, int(slab_first[k])), min(i1, int(slab_first[k + 1]))
+                if a0 < a1:
+                    g0, g1 = s0 + a0 - int(slab_first[k]), s0 + a1 - int(slab_first[k])
+                    out.append(slab_codes[k][int(db.offs[g0] - db.offs[s0]):int(db.offs[g1] - db.offs[s0])])
+            return out[0] if len(out) == 1 else np.concatenate(out)
+        w["codes_of"] = codes_of
         w["index_base"] = 0                                            # one database: indices are global already
         if name == "c4":
             w["text"] = (f"c4: 5478-aa query x Env-NR-shaped database at scale {scale:.4f} ({db.n} sequences, {db.residues} residues), "
                          f"BLOSUM62 g10 e2, top-20; {len(slabs)} slabs dealt statically to {env.world} rank(s)")
+        elif name == "c3":
+            w["text"] = (f"c3: 20-query set (144-5478 aa) x Swiss-Prot-shaped database at scale {scale} ({db.n} sequences, {db.residues} residues, "
+                         f"longest {int(db.lengths[-1])}), BLOSUM50 g10 e2, top-20; {len(slabs)} slabs dealt statically to {env.world} rank(s)")
         else:
             w["text"] = (f"c5: 20-query set (144-5478 aa) x ONE Env-NR-shaped database at scale {scale} ({db.n} sequences, "
                          f"{db.residues} residues), PAM250 g10 e2, top-20; {len(slabs)} slabs dealt statically to {env.world} rank(s)")
@@ -353,22 +423,9 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
         torch.cuda.synchronize()
 
     def exchange(ts, ti):
-        """the path's only exchange step: every rank's top-20 per query -> merged listing (host merge, utils.c order)"""
-        if dist is None:
-            return ts, ti
-        mine_t = torch.from_numpy(np.concatenate([ts.astype(np.int64).ravel(), np.where(ti >= 0, ti + w["index_base"], -1).ravel()]))
-        if env.rccl is not None:
-            mine_t = mine_t.cuda()
-            allv = [torch.empty_like(mine_t) for _ in range(world)]
-            dist.all_gather(allv, mine_t, group=env.rccl)
-        else:
-            allv = [torch.empty_like(mine_t) for _ in range(world)]
-            dist.all_gather(allv, mine_t)
-        g = torch.stack(allv).cpu().numpy()
-        ms = np.zeros((nq, TOP_R), np.int32); mi = np.zeros((nq, TOP_R), np.int64)
-        for k in range(nq):
-            ms[k], mi[k] = host.topr_merge(g[:, k * TOP_R:(k + 1) * TOP_R].astype(np.int32), g[:, (nq + k) * TOP_R:(nq + k + 1) * TOP_R], TOP_R)
-        return ms, mi
+        """the path's only exchange step: every rank's top-20 per query -> merged listing (sharding.allgather_merge: the
+        function the world-size-2 gloo test on the CPU covers; here over the RCCL group when there is one)"""
+        return sharding.allgather_merge(ts, ti, dist, group=env.rccl, index_base=w["index_base"])
 
     def one_step():
         ts, ti, wt = searcher.search_topr(TOP_R, w["n_valid"])
@@ -420,7 +477,19 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
     local_index = w["local_index"]
     mine_scores = full[:, local_index]
     del full
-    ok, stride, n_s, res_s, cpu_s, kind = sample_check(w["qa_list"], w["my_lens"], w["codes_of"], sm, env.threads, lambda idx: mine_scores[:, idx], cpu_budget, my_n)
+    with all_host_cpus(env) as (chk_threads, chk_cores):
+        ok, stride, n_s, res_s, cpu_s, kind, chk_in = sample_check(w["qa_list"], w["my_lens"], w["codes_of"], sm, chk_threads, lambda idx: mine_scores[:, idx], cpu_budget, my_n)
+        m0_gcups = None
+        if world == 1 and want_cpu_baseline:
+            # the product's own -m 0 on a slice of the same sample (it is several times slower than the reference's AVX2 path:
+            # a tenth of the sample keeps it within seconds), same threads
+            o = np.concatenate([[0], np.cumsum(chk_in[0].astype(np.int64))])
+            blocks = range(0, len(chk_in[0]), SAMPLE_BLOCK * 10)
+            sub_l = np.concatenate([chk_in[0][b:b + SAMPLE_BLOCK] for b in blocks])
+            sub_c = np.concatenate([chk_in[1][o[b]:o[min(b + SAMPLE_BLOCK, len(chk_in[0]))]] for b in blocks])
+            m0_gcups = product_m0_gcups(w["qa_list"], sub_l, sub_c, sm, chk_threads)
+            m0_sample = (len(sub_l), int(sub_l.astype(np.int64).sum()))
+        del chk_in
     # the merged top-20 of the timed path (device top-r + exchange) against a host selection over the ranks' full vectors
     hs = np.zeros((nq, TOP_R), np.int32); hi = np.zeros((nq, TOP_R), np.int64)
     for k in range(nq):
@@ -437,24 +506,30 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
     # ---- first search after a cold upload (the reference's workTime brackets the transfers, MICsearch.c:51,350) ----
     # Twice: the first one also pays for the device buffers of the streamed parts (hipMalloc; they go to the library's pool when the
     # database is cleared), the second is what every later re-upload in the process costs.  Both are reported.
-    cold_s = cold_first_s = float("nan")
-    if want_cold:
-        colds = []
-        for _ in range(2):
-            searcher.clear_db()
-            searcher.set_option("lazy_upload", 1)        # chunks stream in while the search runs (what swimm_hip_search_chunks does)
-            barrier()
-            t0 = time.perf_counter()
-            w["upload"](searcher)
-            exchange(*searcher.search_topr(TOP_R, w["n_valid"])[:2])
-            barrier()
-            dt = time.perf_counter() - t0
-            if dist is not None:
-                tmax = torch.tensor([dt], dtype=torch.float64)
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                dt = float(tmax.item())
-            colds.append(dt)
-        cold_first_s, cold_s = colds
+    # want_cold = how many times: the FIRST one also pays for whatever the library allocates for a streamed search (what a
+    # one-shot `swimm -S search` pays: value_incl_h2d); a second one finds the device buffers in the library's pool
+    # (value_incl_h2d_pooled).  N > 1 strong-scaling record: once.
+    colds = []
+    for _ in range(int(want_cold)):
+        searcher.clear_db()
+        searcher.set_option("lazy_upload", 1)        # chunks stream in while the search runs (what swimm_hip_search_chunks does)
+        barrier()
+        t0 = time.perf_counter()
+        w["upload"](searcher)
+        exchange(*searcher.search_topr(TOP_R, w["n_valid"])[:2])
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        colds.append(dt)
+    cold_first_s = colds[0] if colds else float("nan")
+    cold_pooled_s = colds[1] if len(colds) > 1 else float("nan")
+    placement = [(env.rank, env.pci, env.cpus, round(t_up, 3))]
+    if dist is not None:
+        placement = [None] * world
+        dist.all_gather_object(placement, (env.rank, env.pci, env.cpus, round(t_up, 3)))
 
     rec = None
     if rank == 0:
@@ -480,12 +555,14 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
         else:
             per_launch_ms = float(np.mean([ms_ / max(n, 1) for ms_, n in launch_ms]))
             achieved = (alg_bytes / pipe_launches) / (per_launch_ms * 1e-3) / 1e9 if single_kernel else alg_bytes / (k_ms_mean * 1e-3) / 1e9
-            prof = None
+            prof, traffic = None, None
             for d in profs:          # a number from another launch plan is not this run's traffic
                 if single_kernel and d.get("plan") == plan_key and d.get("kernel") == kernel_name and d.get("kernel_launches_per_search") == pipe_launches:
-                    prof = d
+                    prof, traffic = d, d["hbm_bytes_per_launch"]
+                elif not single_kernel and d.get("plans") == plans and d.get("hbm_bytes_per_search"):
+                    prof, traffic = d, d["hbm_bytes_per_search"]       # a query batch: all DP kernels of a search together, like `achieved`
             roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_per": "launch" if single_kernel else "search",
                         "traffic_source": (prof["file"] if prof else "none: no PMC profile of this workload, scale and launch plan is committed (profiles/*_pmc_traffic*.json)"),
                         "kernel": kernel_name, "kernel_ms": round(per_launch_ms, 4), "kernel_launches_per_search": pipe_launches,
                         "device_ms_per_search": round(k_ms_mean, 4), "launches_per_search": launches,
@@ -535,19 +612,22 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
                                                "few 2-cycle scalar-operand ops of a column's overhead, so class_frac is a slight over-estimate of the packed pipe's use"),
                               "kernel_only_gcups": round(kernel_gcups, 2), "padded_cells": float(stats["cells"])},
             "search_call_ms": round(float(np.mean(wts)) * 1e3, 4),
-            "value_incl_h2d": round(q_real * total_residues / cold_s / 1e9, 2) if want_cold else None,
-            "value_incl_h2d_first": round(q_real * total_residues / cold_first_s / 1e9, 2) if want_cold else None,
-            "value_incl_h2d_note": (f"first search after a cold upload of the shard (pageable host memory, {w['upload_kind']}; chunk k+1 copied and tiled while chunk k is aligned): "
-                                    f"{cold_s * 1e3:.1f} ms with the device buffers coming from the library's pool (second cold upload of the process), "
-                                    f"{cold_first_s * 1e3:.1f} ms the first time (value_incl_h2d_first: fresh hipMalloc of the streamed parts)" if want_cold else None),
-            "h2d_upload_s": round(t_up, 3), "datagen_s": round(w["datagen_s"], 2), "searches_in_run": n_searches + (2 if want_cold else 0),
+            "value_incl_h2d": round(q_real * total_residues / cold_first_s / 1e9, 2) if colds else None,
+            "value_incl_h2d_pooled": round(q_real * total_residues / cold_pooled_s / 1e9, 2) if len(colds) > 1 else None,
+            "value_incl_h2d_ms": [round(x * 1e3, 2) for x in colds],
+            "value_incl_h2d_note": ((f"search_topr right after a cold upload of the shard (pageable host memory, {w['upload_kind']}; the chunks stream in while the search runs), "
+                                     "clock around add_* + search: value_incl_h2d = the FIRST cold search of the process (rounds 1-3 reported the pooled one under this key), "
+                                     "value_incl_h2d_pooled = the second (device buffers from the library's pool)") if colds else None),
+            "h2d_upload_s": round(t_up, 3), "datagen_s": round(w["datagen_s"], 2), "searches_in_run": n_searches + len(colds),
             "plans": plans if nq > 1 else None,
             "top1": [int(top_s[0][0]), int(top_i[0][0])],
             "bit_exact_vs_reference": all_ok, "merged_top20_matches_full_vectors": all_top_ok,
-            "parity_sample": f"every rank: every {stride}th sequence of its shard x all queries vs the CPU {kind} ({n_s} sequences, {res_s} residues on rank 0)",
+            "parity_sample": (f"every rank: " + ("every sequence" if stride == 1 else f"every {stride}th block of {SAMPLE_BLOCK} consecutive sequences") +
+                              f" of its shard x all queries vs the CPU {kind} ({n_s} sequences, {res_s} residues on rank 0)"),
         }
         if roofline_note:
             rec["roofline_note"] = roofline_note
+        rec["placement"] = [{"rank": r_, "pci": pci_, "cpus": cpus_, "eager_upload_s": up_} for r_, pci_, cpus_, up_ in placement]
         if world > 1:
             rec["per_rank_kernel_gcups"] = [round(x[0], 2) for x in per_rank]
             rec["per_rank_kernel_gcups_min"] = round(min(x[0] for x in per_rank), 2)
@@ -558,9 +638,13 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
                 model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
             except Exception:
                 model = "unknown"
-            rec["cpu_baseline"] = {"value": round(q_real * res_s / cpu_s / 1e9, 2), "unit": "GCUPS", "cores": env.cores, "threads": env.threads,
+            rec["cpu_baseline"] = {"value": round(q_real * res_s / cpu_s / 1e9, 2), "unit": "GCUPS", "cores": chk_cores, "threads": chk_threads,
                                    "kind": kind, "cpu_model": model, "matches_gpu": ok,
-                                   "sample": f"{name} shard, every {stride}th sequence ({n_s} sequences, {res_s} residues), {nq} quer{'y' if nq == 1 else 'ies'}, {cpu_s:.2f} s"}
+                                   "sample": (f"{name} shard, " + ("every sequence" if stride == 1 else f"every {stride}th block of {SAMPLE_BLOCK} consecutive sequences") +
+                                              f" ({n_s} sequences, {res_s} residues), {nq} quer{'y' if nq == 1 else 'ies'}, {cpu_s:.2f} s"),
+                                   "product_m0": round(m0_gcups, 2) if m0_gcups else None,
+                                   "product_m0_note": (f"the product's own -m 0 (swimm_cpu_search: int32 lanes, auto-vectorised) on {m0_sample[0]} sequences / {m0_sample[1]} residues of the same sample, "
+                                                       f"{chk_threads} threads: the host leg of `swimm -m 2` and all of BASELINE config 1; the reference's AVX2 path beside it is `value`")}
     searcher.close()
     if w["chunks"] is not None:
         w["chunks"].close()
@@ -574,9 +658,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=("c2", "c4", "c5"), default=None,
+    ap.add_argument("--workload", choices=("c2", "c3", "c4", "c5"), default=None,
                     help="run this configuration alone (default: c2 at the top level + the secondary / strong-scaling records)")
-    ap.add_argument("--scale", type=float, default=None, help="fraction of the configuration's database (default: c2 1.0, c4 0.186, c5 0.25); with --workload")
+    ap.add_argument("--scale", type=float, default=None, help="fraction of the configuration's database (default: c2 1.0, c3 1.0, c4 1.0, c5 0.25); with --workload")
     ap.add_argument("--strong-scale", type=float, default=1.0, help="scale of the c5 database of the strong_scaling record at N > 1")
     ap.add_argument("--secondary-steps", type=int, default=2)
     ap.add_argument("--secondary-scale", type=float, default=1.0, help="multiplies the default scales of the secondary records (tests: small databases)")
@@ -602,24 +686,26 @@ def main():
     if args.scale is not None and not args.workload:
         scale = args.scale                  # (--scale without --workload: a smaller c2, for rehearsals)
     baseline = world == 1 and not args.no_cpu_baseline
-    rec, ok = run_workload(env, args, primary, scale, args.steps, args.warmup, 25.0 if baseline else 6.0, not args.no_cold, baseline)
+    n_cold = 0 if args.no_cold else 2
+    rec, ok = run_workload(env, args, primary, scale, args.steps, args.warmup, 25.0 if baseline else 6.0, n_cold, baseline)
     all_ok = ok
     extra = {}
     if not args.workload and not args.no_secondary:
         if world == 1:
             secondary = []
-            for name in ("c4", "c5"):
-                r2, ok2 = run_workload(env, args, name, DEFAULT_SCALE[name] * args.secondary_scale, args.secondary_steps, 1, 10.0, not args.no_cold, baseline)
+            for name in ("c3", "c4", "c5"):
+                r2, ok2 = run_workload(env, args, name, DEFAULT_SCALE[name] * args.secondary_scale, args.secondary_steps, 1, 10.0, n_cold, baseline)
                 all_ok = all_ok and ok2
                 r2["workload"] = name
                 # (the line must stay well inside what a caller keeps of stdout -- gpurun: 24 000 characters: the texts that the top-level
                 # record already carries are not repeated)
-                for obj, keys in ((r2.get("roofline") or {}, ("note",)), (r2["valu_roofline"], ("peak_source", "class_source"))):
+                for obj, keys in ((r2.get("roofline") or {}, ("note",)), (r2["valu_roofline"], ("peak_source", "class_source", "instructions")), (r2, ("value_incl_h2d_note", "placement")),
+                                  (r2.get("cpu_baseline") or {}, ("product_m0_note", "cpu_model"))):
                     for k in keys:
                         obj.pop(k, None)
                 secondary.append(r2)
             extra["secondary"] = secondary
-            c5 = secondary[1]
+            c5 = secondary[2]
             # the N = 1 point of north_star's strong-scaling series (GCUPS and HBM fraction at 1, 2, 4, 8 GPUs): the c5 record above, at a
             # quarter of the database so that the line stays within minutes (`--workload c5 --scale 1` runs the whole database on one GPU)
             extra["strong_scaling"] = {
@@ -630,7 +716,7 @@ def main():
                 "rccl_ranks": 0, "topr_exchange": "none", "bit_exact": c5["bit_exact_vs_reference"] and c5["merged_top20_matches_full_vectors"],
                 "note": "N = 1 at a quarter of the database (at N > 1 the whole 7e9-residue database is sharded: --strong-scale 1); GCUPS does not depend on the scale from 10 % up (profiles/r03_bench_c5_full.json: the whole database on one GPU)"}
         else:
-            r2, ok2 = run_workload(env, args, "c5", args.strong_scale, args.secondary_steps, 1, 6.0, False, False)
+            r2, ok2 = run_workload(env, args, "c5", args.strong_scale, args.secondary_steps, 1, 6.0, 0 if args.no_cold else 1, False)
             all_ok = all_ok and ok2
             if env.rank == 0:
                 extra["strong_scaling"] = {
@@ -643,6 +729,7 @@ def main():
                     "rccl_ranks": env.rccl_ranks, "topr_exchange": r2["config"]["topr_exchange"],
                     "bit_exact": r2["bit_exact_vs_reference"] and r2["merged_top20_matches_full_vectors"], "parity_sample": r2["parity_sample"],
                     "plans": r2["plans"], "db_residues_total": r2["config"]["db_residues_total"], "datagen_s": r2["datagen_s"], "h2d_upload_s": r2["h2d_upload_s"],
+                    "value_incl_h2d": r2["value_incl_h2d"], "value_incl_h2d_ms": r2["value_incl_h2d_ms"], "placement": r2["placement"],
                 }
     if env.rank == 0:
         out = {"metric": METRIC, "value": rec["value"], "unit": "GCUPS", "n_gpus": world, "steps": rec["steps"], "warmup": rec["warmup"],
@@ -659,7 +746,28 @@ def main():
         if env.share:
             out["shared_device"] = True
             out["note"] = "REHEARSAL: all ranks share GPU 0 (SWIMM_BENCH_SHARE_DEVICE=1); the value is not a multi-GPU figure"
-        print(json.dumps(out), file=json_out, flush=True)
+        # the headline figures of every record once more, LAST in the line and short: a caller that keeps only the tail of
+        # stdout still sees the configurations, their sizes and whether they matched the reference
+        def brief(r, key):
+            return {"workload": key, "scale": r["config"]["scale"], "db_residues": r["config"]["db_residues_total"], "queries": r["config"]["queries"],
+                    "value": r["value"], "kernel_only": r["valu_roofline"]["kernel_only_gcups"], "value_incl_h2d": r.get("value_incl_h2d"),
+                    "value_incl_h2d_pooled": r.get("value_incl_h2d_pooled"), "ms_per_step": r["ms_per_step"],
+                    "hbm_frac": (r["roofline"] or {}).get("frac"), "valu_class_frac": r["valu_roofline"]["class_frac"],
+                    "bit_exact_vs_reference": r["bit_exact_vs_reference"] and r["merged_top20_matches_full_vectors"],
+                    "cpu_reference_gcups": (r.get("cpu_baseline") or {}).get("value"), "cpu_product_m0_gcups": (r.get("cpu_baseline") or {}).get("product_m0")}
+        out["summary"] = [brief(rec, primary)] + [brief(r, r["workload"]) for r in extra.get("secondary", [])]
+        if world > 1 and "strong_scaling" in extra:
+            ss = extra["strong_scaling"]
+            out["summary"].append({"workload": "c5 strong scaling", "scale": ss["scale"], "n_gpus": world, "value": ss["value"], "value_incl_h2d": ss.get("value_incl_h2d"),
+                                   "rccl_ranks": ss["rccl_ranks"], "bit_exact": ss["bit_exact"], "hbm_frac": ss["hbm_frac"]})
+        line = json.dumps(out)
+        print(line, file=json_out, flush=True)
+        try:                             # (kept beside the profiles of a gpurun call; never read back)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_last_n{world}.json"), "w") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
     if env.dist is not None:
         env.dist.barrier()
         env.dist.destroy_process_group()

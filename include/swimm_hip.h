@@ -50,6 +50,19 @@ const char *swimm_hip_last_error(void);
  * no GPU is usable). */
 int swimm_hip_device_count(void);
 
+/* PCI address of a visible device as sysfs spells it ("0000:0c:00.0"), so that a multi-process caller can tell which
+ * physical devices its ranks sit on and which CPUs are local to each.  No reference counterpart. */
+int swimm_hip_device_pci_bus_id(int device, char *buf, size_t buf_len);
+
+/* Binds the CALLING host thread -- and the threads it creates from here on: the context's uploader thread, an OpenMP team --
+ * to the CPUs local to `device`, one of the `num_devices` devices 0..num_devices-1 this process drives: the device's sysfs
+ * local_cpulist, shared by whole physical cores with the other devices that name the same CPUs; an even share of the
+ * thread's allowed CPUs when sysfs says nothing (swimm_amd/csrc/host/affinity.h).  Call it from the device's host thread
+ * before swimm_hip_create.  swimm_hip_search_chunks does so for its per-device threads.  `cpulist_out` (may be NULL) gets
+ * the CPUs in "0-7,128-135" form.  SWIMM_HIP_BIND=0 in the environment makes it a no-op (a scheduler already placed the
+ * process).  The reference leaves its per-MIC host threads to the OpenMP runtime (MICsearch.c:53). */
+int swimm_hip_bind_host_thread(int device, int num_devices, char *cpulist_out, size_t cpulist_len);
+
 /* Per-device state: stream, scratch.  Replaces the per-MIC host thread prologue
  * `#pragma offload_transfer ... ALLOC` (MICsearch.c:53-71). */
 int swimm_hip_create(int device, swimm_hip_ctx **out);

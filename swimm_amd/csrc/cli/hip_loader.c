@@ -55,6 +55,7 @@ int swimm_hip_load(swimm_hip_api *api, char *err, unsigned long err_len)
     BIND(last_stats, "swimm_hip_last_stats");
     BIND(last_plan, "swimm_hip_last_plan");
     BIND(set_option, "swimm_hip_set_option");
+    BIND(bind_host_thread, "swimm_hip_bind_host_thread");
     if (api->abi_version() != SWIMM_HIP_ABI_VERSION) {
         snprintf(err, err_len, "SWIMM: %s has ABI version %d, this program needs %d", path, api->abi_version(), SWIMM_HIP_ABI_VERSION);
         return 1;

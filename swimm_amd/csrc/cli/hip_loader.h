@@ -20,6 +20,7 @@ typedef struct {
     int (*last_stats)(swimm_hip_ctx *, double *, uint64_t *, uint64_t *, uint32_t *);
     int (*last_plan)(swimm_hip_ctx *, uint32_t, int *, int *, int *);
     int (*set_option)(swimm_hip_ctx *, const char *, int);
+    int (*bind_host_thread)(int, int, char *, size_t);
 } swimm_hip_api;
 
 /* Looks for $SWIMM_HIP_LIB, then <dir of the executable>/../lib/libswimm_hip.so, then the loader path.

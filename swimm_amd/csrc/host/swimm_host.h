@@ -132,6 +132,16 @@ int swimm_cpu_search(const char *a, const uint16_t *m, uint64_t query_count, con
 const char *swimm_submat(const char *name);
 const char *swimm_submat_label(const char *name);
 
+/* ---- CPU placement of the host threads that serve one GPU (affinity.h: the device's sysfs local_cpulist, shared by whole
+ * physical cores among the devices that name the same CPUs; an even share of the allowed CPUs when sysfs says nothing).
+ * The reference leaves its per-device host threads to the OpenMP runtime (MICsearch.c:53).  plan: pure (sysfs_root = "/sys"
+ * in production), returns the number of CPUs written or -1; allowed: the calling thread's current CPUs; apply:
+ * sched_setaffinity of the calling thread (threads created afterwards inherit it). ---- */
+int swimm_affinity_plan(const char *sysfs_root, const char *const *pci_bdf, int n_devices, int device, const int *allowed, int n_allowed,
+                        int *out_cpus, int cap);
+int swimm_affinity_allowed(int *out, int cap);
+int swimm_affinity_apply(const int *cpus, int n);
+
 /* wall clock (dwalltime, utils.c:89-97) */
 double swimm_wtime(void);
 

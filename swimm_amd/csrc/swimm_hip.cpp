@@ -8,6 +8,7 @@
 // Structural template: mic_search_knc_ap_multiple_chunks (MICsearch.c:4-354) -- X1 = set_queries,
 // X2-in = add_chunk (kept resident), compute = search, X3 = scatter into the caller's scores.
 #include "swimm_impl.h"
+#include "host/affinity.h"
 
 thread_local std::string swimm_impl::g_err;
 thread_local int swimm_impl::g_cur_vdevice = -1;
@@ -35,6 +36,45 @@ int swimm_hip_device_count(void)
     if (e != hipSuccess) { fail("hipGetDeviceCount: %s", hipGetErrorString(e)); return 0; }
     if (n == 0) fail("no HIP device visible");
     return virtual_gpus(n);
+}
+
+int swimm_hip_device_pci_bus_id(int device, char *buf, size_t buf_len)
+{
+    if (!buf || buf_len < 13) return fail("swimm_hip_device_pci_bus_id: buffer of at least 13 bytes needed");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= virtual_gpus(n)) return fail("swimm_hip_device_pci_bus_id: device %d not in [0,%d)", device, virtual_gpus(n));
+    HIP_TRY(hipDeviceGetPCIBusId(buf, (int)buf_len, device % std::max(n, 1)));
+    for (char *p = buf; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');      // sysfs spells the address in lower case
+    return 0;
+}
+
+int swimm_hip_bind_host_thread(int device, int num_devices, char *cpulist_out, size_t cpulist_len)
+{
+    if (cpulist_out && cpulist_len) cpulist_out[0] = 0;
+    if (num_devices <= 0 || device < 0 || device >= num_devices) return fail("swimm_hip_bind_host_thread: device %d of %d", device, num_devices);
+    const char *off = getenv("SWIMM_HIP_BIND");
+    if (off && !strcmp(off, "0")) return 0;
+    std::vector<std::string> bdf(num_devices);
+    std::vector<const char *> bdf_p(num_devices, nullptr);
+    for (int d = 0; d < num_devices; ++d) {
+        char b[64] = "";
+        if (swimm_hip_device_pci_bus_id(d, b, sizeof b) == 0) bdf[d] = b;       // (a device the runtime cannot name takes the even share)
+        bdf_p[d] = bdf[d].c_str();
+    }
+    std::vector<int> allowed(SWIMM_AFF_MAX_CPUS), mine(SWIMM_AFF_MAX_CPUS);
+    const int na = swimm_affinity_allowed_impl(allowed.data(), (int)allowed.size());
+    if (na <= 0) return fail("swimm_hip_bind_host_thread: sched_getaffinity failed");
+    const int nm = swimm_affinity_plan_impl("/sys", bdf_p.data(), num_devices, device, allowed.data(), na, mine.data(), (int)mine.size());
+    if (nm <= 0) return fail("swimm_hip_bind_host_thread: no CPU for device %d", device);
+    if (swimm_affinity_apply_impl(mine.data(), nm) != 0) return fail("swimm_hip_bind_host_thread: sched_setaffinity failed");
+    if (cpulist_out && cpulist_len) swimm_affinity_format(mine.data(), nm, cpulist_out, cpulist_len);
+    if (getenv("SWIMM_HIP_DEBUG")) {
+        char txt[512];
+        swimm_affinity_format(mine.data(), nm, txt, sizeof txt);
+        fprintf(stderr, "swimm_hip: host thread of device %d (%s) of %d bound to CPUs %s\n", device, bdf_p[device], num_devices, txt);
+    }
+    return 0;
 }
 
 int swimm_hip_create(int device, swimm_hip_ctx **out)
@@ -554,6 +594,9 @@ int swimm_hip_search_chunks(const char *query_sequences, const uint16_t *query_s
             if (shard[g].empty()) return;
             swimm_hip_ctx *ctx = nullptr;
             auto bail = [&]() { errs[g] = swimm_hip_last_error(); if (ctx) swimm_hip_destroy(ctx); };
+            // this thread, and the uploader thread its context starts, on the CPUs local to the device (best effort: a host
+            // without the sysfs files gets the even share, a failure to bind is not a failure to search)
+            (void)swimm_hip_bind_host_thread(g, num_gpus, nullptr, 0);
             if (swimm_hip_create(g, &ctx)) return bail();
             // the caller's chunks outlive this call: stream them in while the search runs (X2 overlapped with compute)
             if (swimm_hip_set_option(ctx, "lazy_upload", 1)) return bail();

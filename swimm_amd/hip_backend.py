@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "swimm_hip_destroy", "swimm_hip_set_queries", "swimm_hip_add_chunk", "swimm_hip_add_sequences", "swimm_hip_clear_db",
     "swimm_hip_search", "swimm_hip_search_topr", "swimm_hip_last_stats", "swimm_hip_last_plan", "swimm_hip_last_kernel_name", "swimm_hip_last_launch_ms",
     "swimm_hip_set_option",
-    "swimm_hip_search_chunks",
+    "swimm_hip_search_chunks", "swimm_hip_device_pci_bus_id", "swimm_hip_bind_host_thread",
 )
 
 
@@ -63,6 +63,20 @@ def device_count() -> int:
     if n <= 0:
         raise SwimmHipError(load_library().swimm_hip_last_error().decode() or "no GPU")
     return n
+
+
+def device_pci_bus_id(device: int) -> str:
+    """sysfs spelling of the device's PCI address ("0000:0c:00.0")"""
+    buf = C.create_string_buffer(64)
+    _check(load_library().swimm_hip_device_pci_bus_id(C.c_int(device), buf, C.c_size_t(64)))
+    return buf.value.decode()
+
+
+def bind_host_thread(device: int, num_devices: int) -> str:
+    """binds the calling thread (and the threads it starts later) to the CPUs local to `device`; -> the CPU list"""
+    buf = C.create_string_buffer(1024)
+    _check(load_library().swimm_hip_bind_host_thread(C.c_int(device), C.c_int(num_devices), buf, C.c_size_t(1024)))
+    return buf.value.decode()
 
 
 class HipSearcher:

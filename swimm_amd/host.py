@@ -20,6 +20,7 @@ HOST_SYMBOLS = (
     "swimm_db_load", "swimm_db_free", "swimm_db_titles", "swimm_queries_load", "swimm_queries_free",
     "swimm_assemble_single_chunk", "swimm_single_chunk_free", "swimm_assemble_chunks", "swimm_chunks_free",
     "swimm_topr", "swimm_topr_merge", "swimm_cpu_search", "swimm_submat", "swimm_submat_label", "swimm_wtime",
+    "swimm_affinity_plan", "swimm_affinity_allowed", "swimm_affinity_apply",
 )
 
 
@@ -218,3 +219,36 @@ def topr_merge(scores, idx, r: int):
     out_i = np.zeros(r, dtype=np.int64)
     lib().swimm_topr_merge(_p(sc), _p(ix), C.c_uint32(lists), C.c_uint32(r), _p(out_s), _p(out_i))
     return out_s, out_i
+
+
+def _cpulist(cpus) -> str:
+    """[0, 1, 2, 3, 8] -> '0-3,8'"""
+    out, i, cpus = [], 0, list(cpus)
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(f"{cpus[i]}-{cpus[j]}" if j > i else f"{cpus[i]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def affinity_plan(pci_bdf, device: int, allowed=None, sysfs_root: str = "/sys"):
+    """CPUs for the host threads of device `device` of len(pci_bdf) devices (affinity.h: the device's sysfs local_cpulist,
+    shared by whole physical cores among the devices naming the same CPUs; an even share of `allowed` otherwise)."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else list(allowed)
+    n = len(pci_bdf)
+    arr = (C.c_char_p * n)(*[(b or "").encode() for b in pci_bdf])
+    al = np.ascontiguousarray(allowed, dtype=np.int32)
+    out = np.zeros(4096, dtype=np.int32)
+    got = lib().swimm_affinity_plan(sysfs_root.encode(), arr, C.c_int(n), C.c_int(device), _p(al), C.c_int(len(al)), _p(out), C.c_int(len(out)))
+    if got <= 0:
+        raise SwimmHostError(f"no CPU plan for device {device} of {n}")
+    return [int(x) for x in out[:got]]
+
+
+def affinity_apply(cpus):
+    """binds the calling thread (threads started afterwards inherit it)"""
+    a = np.ascontiguousarray(list(cpus), dtype=np.int32)
+    if lib().swimm_affinity_apply(_p(a), C.c_int(len(a))) != 0:
+        raise SwimmHostError("sched_setaffinity failed")

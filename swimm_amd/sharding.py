@@ -61,17 +61,20 @@ def search_topr_local(engine, q, chunks, owner, rank, sm, open_gap, extend_gap, 
     return ts, ti
 
 
-def allgather_merge(ts, ti, dist=None):
-    """merge per-rank [nq, r] lists; with torch.distributed (any backend) every rank gets the result"""
+def allgather_merge(ts, ti, dist=None, group=None, index_base=0):
+    """The path's only exchange step: every rank's top-r per query -> the merged listing on every rank (host merge, utils.c
+    order).  `dist`: torch.distributed (any backend) or None for one rank; `group`: the process group that carries the lists
+    (bench.py: the RCCL group; default: the default group); tensors live where that group's backend needs them.
+    `index_base` is added to this rank's indices first (ranks that hold disjoint databases number their sequences from 0)."""
     nq, r = ts.shape
     if dist is None or dist.get_world_size() == 1:
         return ts, ti
     import torch
-    mine = torch.from_numpy(np.concatenate([ts.astype(np.int64).ravel(), ti.ravel()]))
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.from_numpy(np.concatenate([ts.astype(np.int64).ravel(), np.where(ti >= 0, ti + index_base, -1).astype(np.int64).ravel()]))
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     mine = mine.to(dev)
-    allv = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(allv, mine)
+    allv = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(allv, mine, group=group)
     g = torch.stack(allv).cpu().numpy()
     ms = np.zeros((nq, r), np.int32); mi = np.zeros((nq, r), np.int64)
     for qi in range(nq):

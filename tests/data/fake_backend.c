@@ -110,3 +110,4 @@ int swimm_hip_last_stats(swimm_hip_ctx *c, double *kernel_ms, uint64_t *cells, u
 
 int swimm_hip_last_plan(swimm_hip_ctx *c, uint32_t q, int *t, int *w, int *p) { (void)c; (void)q; if (t) *t = 0; if (w) *w = 0; if (p) *p = 0; return 0; }
 int swimm_hip_set_option(swimm_hip_ctx *c, const char *key, int value) { (void)c; (void)key; (void)value; return 0; }
+int swimm_hip_bind_host_thread(int device, int num_devices, char *cpulist_out, size_t len) { (void)device; (void)num_devices; if (cpulist_out && len) cpulist_out[0] = 0; return 0; }

@@ -29,7 +29,9 @@ def _worker(rank, world, port, prefix, qfa, r, outdir):
     owner = sharding.assign_chunks([c["vD"] for c in ch.chunks], world)
     assert set(owner.tolist()) == set(range(world))          # every rank got work
     ts, ti = sharding.search_topr_local("cpu", q, ch.chunks, owner, rank, submat.table("blosum62"), 10, 2, r, db["count"])
-    ms, mi = sharding.allgather_merge(ts, ti, dist)
+    # (bench.py hands over the process group that carries the lists -- its RCCL group; here a gloo subgroup stands in for it)
+    grp = dist.new_group(ranks=list(range(world)), backend="gloo") if r == 100 else None
+    ms, mi = sharding.allgather_merge(ts, ti, dist, group=grp)
     np.save(os.path.join(outdir, f"s{rank}.npy"), ms); np.save(os.path.join(outdir, f"i{rank}.npy"), mi)
     np.save(os.path.join(outdir, f"own{rank}.npy"), owner)
     ch.close()
@@ -59,3 +61,26 @@ def test_assign_chunks_is_balanced_lpt():
     loads = [sum(s for s, o in zip(sizes, owner) if o == g) for g in range(3)]
     assert sorted(loads) == [100, 100, 105] and owner.tolist()[:3] == [0, 1, 2]
     assert sharding.assign_chunks([7], 4).tolist() == [0]
+
+
+def _worker_disjoint(rank, world, port, outdir):
+    """ranks that hold DISJOINT databases (bench.py's weak-scaling c2: every rank numbers its sequences from 0)"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from swimm_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ts = np.array([[50 - rank, 40, 30 + rank], [7, 7, -1]], np.int32)      # second query: a short list (one empty slot)
+    ti = np.array([[5, 3, 1], [9, 2, -1]], np.int64)
+    ms, mi = sharding.allgather_merge(ts, ti, dist, index_base=rank * 1000)
+    np.save(os.path.join(outdir, f"ds{rank}.npy"), ms); np.save(os.path.join(outdir, f"di{rank}.npy"), mi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_merge_of_disjoint_databases_offsets_the_indices(tmp_path):
+    mp.spawn(_worker_disjoint, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        ms, mi = np.load(tmp_path / f"ds{rank}.npy"), np.load(tmp_path / f"di{rank}.npy")
+        assert ms.tolist() == [[50, 49, 40], [7, 7, 7]]
+        assert mi.tolist() == [[5, 1005, 1003], [1009, 1002, 9]]            # ties: the larger index first (utils.c:12,52)

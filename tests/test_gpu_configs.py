@@ -98,6 +98,50 @@ def test_c4_long_query_envnr_shape():
     _check_matrix(got[:, :w["n"]], want, idx, "c4")
 
 
+def test_c4_envnr_quarter_of_the_target_database():
+    """north_star's target configuration (BASELINE config 4: the 5 478-residue query x the Env-NR-shaped database, BLOSUM62
+    10/2) at a QUARTER of its 7e9 residues -- 8.9 M sequences / 1.75e9 residues, 69 000 device groups -- the first search
+    streamed in from .seq slabs while it runs, the second on the resident copy: both must give the same 8.9 M scores, the
+    planted copies of the query their known answers, and a block sample of the database (every k-th block of 64 consecutive
+    sequences, k from the host's cores) the reference's own scores."""
+    db = workloads.SortedDb("c4", 0.25)
+    assert int(db.m[0]) == 5478 and db.residues > 0.25 * 6.9e9 and db.n > 8_800_000
+    sm = matrix(db.matrix)
+    slabs = db.slabs(8)
+    stride_slots = (db.n + 127) // 128 * 128
+    with hip_backend.HipSearcher(0) as s:
+        s.set_queries(db.a, db.m, db.disp, sm, 10, 2)
+        s.set_option("lazy_upload", 1)
+        keep = []
+        for s0, s1, _ in slabs:
+            keep.append(db.codes(s0, s1))
+            s.add_sequences(db.lengths[s0:s1], keep[-1], first_seq=s0)
+        cold, _ = s.search(stride_slots)
+        cold_launches = s.last_stats()["launches"]
+        warm, _ = s.search(stride_slots)
+        ts, ti, _ = s.search_topr(20, db.n)
+        plan = s.last_plan(0)
+    assert np.array_equal(cold, warm), "the streamed first search and the resident search differ"
+    got = warm[0, :db.n]
+    assert plan["passes"] >= 12 and cold_launches >= 2
+    # known answers: the exact copy of the query scores its self score and leads the listing, ahead of the mutated copies
+    self_score = port.pair_score(db.a, db.a, sm, 10, 2)
+    assert int(ts[0][0]) == self_score == int(got.max()) and ts[0][0] > ts[0][1] > ts[0][2] > ts[0][3]
+    os_, oi = port.topr(got, 20)
+    assert np.array_equal(ts[0], os_) and np.array_equal(ti[0], oi)
+    # block sample against the reference: ~20 s of the host's cores at about 1 GCUPS per hardware thread
+    threads = len(os.sched_getaffinity(0))
+    k = max(1, int(np.ceil(5478.0 * db.residues / (1.0e9 * threads * 20.0))))
+    starts = np.arange(0, db.n, 64 * k, dtype=np.int64)
+    idx = np.concatenate([np.arange(b, min(b + 64, db.n), dtype=np.int64) for b in starts])
+    sub = {"lengths": db.lengths[idx], "codes": np.concatenate([db.codes(int(b), int(min(b + 64, db.n))) for b in starts]), "n": len(idx),
+           "residues": int(db.lengths[idx].astype(np.int64).sum()), "a": db.a, "m": db.m, "disp": db.disp, "query_residues": 5478, "matrix": db.matrix}
+    sub["offs"] = np.concatenate([[0], np.cumsum(sub["lengths"].astype(np.int64))])
+    want, widx = oracle_matrix(sub, budget_s=1e9)
+    assert len(widx) == len(idx) and sub["residues"] > 1e6
+    _check_matrix(got[None, idx], want, np.arange(len(idx)), f"c4 at a quarter of 7e9 residues (every {k}th block of 64)")
+
+
 def test_c5_envnr_pam250_eight_way_shard(monkeypatch):
     G = 8
     w = workloads.build("c5", 0, n_sequences=320_000)

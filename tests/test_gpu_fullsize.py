@@ -94,10 +94,18 @@ def test_bench_line_contract():
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["matches_gpu"] is True
     assert d["roofline"]["frac"] <= 1.0 and d["bit_exact_vs_reference"] is True
-    # the Env-NR-shaped configurations ride on the same line, each with its own parity sample, roofline and CPU baseline
-    assert [r["workload"] for r in d["secondary"]] == ["c4", "c5"]
+    # the other BASELINE configurations ride on the same line, each with its own parity sample, roofline and CPU baseline
+    assert [r["workload"] for r in d["secondary"]] == ["c3", "c4", "c5"]
     for r in d["secondary"]:
         assert r["bit_exact_vs_reference"] is True and r["merged_top20_matches_full_vectors"] is True and r["value"] > 100
         assert r["cpu_baseline"]["matches_gpu"] is True and r["cpu_baseline"]["kind"] in ("reference", "port")
         assert r["roofline"] is None and "roofline_note" in r or (0 < r["roofline"]["frac"] <= 1.0 and "sw_" in r["roofline"]["kernel"])
-    assert d["secondary"][0]["config"]["queries"] == 1 and d["secondary"][1]["config"]["queries"] == 20
+        assert r["value_incl_h2d"] > 10 and r["value_incl_h2d_pooled"] > 10
+    assert [r["config"]["queries"] for r in d["secondary"]] == [20, 1, 20]
+    assert d["cpu_baseline"]["product_m0"] > 0
+    # the first cold search of the process under value_incl_h2d, the pooled one beside it; where the rank's threads sit
+    assert d["value_incl_h2d"] > 10 and d["value_incl_h2d_pooled"] > 10 and len(d["value_incl_h2d_ms"]) == 2
+    assert d["placement"][0]["rank"] == 0 and d["placement"][0]["pci"]
+    # ... and the line ENDS with the short summary of every record
+    assert list(d.keys())[-1] == "summary" and [x["workload"] for x in d["summary"]] == ["c2", "c3", "c4", "c5"]
+    assert all(x["bit_exact_vs_reference"] is True for x in d["summary"]) and len(json.dumps(d["summary"])) < 2500

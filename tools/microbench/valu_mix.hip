@@ -109,10 +109,11 @@ int main()
     for (auto &e : ks) {
         double cyc[4] = {0, 0, 0, 0};
         for (int mode = 0; mode < 4; ++mode) {
-            hipLaunchKernelGGL(e.k, dim3(cus), dim3(1024), 0, 0, out, 1u, mode);
+            // (warm: the first launches after an idle moment run at a lower clock than the one block 0 reports at the end)
+            for (int rep = 0; rep < 10; ++rep) hipLaunchKernelGGL(e.k, dim3(cus), dim3(1024), 0, 0, out, 1u, mode);
             hipDeviceSynchronize();
             hipEventRecord(e0);
-            for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL(e.k, dim3(cus), dim3(1024), 0, 0, out, 1u, mode);
+            for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL(e.k, dim3(cus), dim3(1024), 0, 0, out, 1u, mode);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms = 0;
@@ -121,7 +122,7 @@ int main()
             hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof clk);
             const double ghz = (double)clk[0] / (double)clk[1] * 0.1;
             // SIMD cycles of one launch; per instruction: modes 0-2 issue 4 N instructions per SIMD, mode 3 issues 8 N
-            const double simd_cycles = ms * 1e-3 / 5.0 * ghz * 1e9;
+            const double simd_cycles = ms * 1e-3 / 20.0 * ghz * 1e9;
             cyc[mode] = simd_cycles / ((mode == 3 ? 8.0 : 4.0) * ITER * UNROLL);
         }
         if (!printed_map) {

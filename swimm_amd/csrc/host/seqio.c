@@ -290,11 +290,30 @@ int swimm_preprocess_db(const char *fasta_path, const char *out_prefix, uint64_t
         fd = fopen(name, "wb");
         if (!fd) { rc = FAIL(SWIMM_E_FILE, "SWIMM: An error occurred while opening sequence header file."); goto done; }
         (void)setvbuf(fd, NULL, _IOFBF, (size_t)4 << 20);
+        /* ... and beside it <out>.didx, this build's sidecar (not one of the reference's three files, which stay byte-identical;
+         * optional on read): where every title line starts, so that a report's r titles are r seeks instead of a walk through
+         * the whole file (the reference reads all N titles, sequences.c:757-761).  Header: "SWIMDIDX", N, size of .desc. */
+        snprintf(name, sizeof name, "%s.didx", out_prefix);
+        FILE *fx = fopen(name, "wb");
+        uint64_t at = 0;
+        if (fx) {
+            (void)setvbuf(fx, NULL, _IOFBF, (size_t)4 << 20);
+            const uint64_t hdr[3] = {SWIMM_DIDX_MAGIC, x.n, 0};
+            fwrite(hdr, sizeof hdr, 1, fx);
+        }
         for (uint64_t i = 0; i < x.n; ++i) {
             const uint64_t s = order[i];
             if (x.title_len[s] > max_title) max_title = x.title_len[s];
             fwrite(tit + x.title_off[s], 1, x.title_len[s], fd);
             fputc('\n', fd);
+            if (fx) fwrite(&at, sizeof at, 1, fx);
+            at += x.title_len[s] + 1;
+        }
+        if (fx) {                      /* (a sidecar that could not be written whole is removed: the reader then walks the file) */
+            int bad = ferror(fx);
+            if (!bad) bad = fseek(fx, 16, SEEK_SET) != 0 || fwrite(&at, sizeof at, 1, fx) != 1;
+            bad = fclose(fx) != 0 || bad;
+            if (bad) { snprintf(name, sizeof name, "%s.didx", out_prefix); (void)remove(name); }
         }
         if (ferror(fd)) { rc = FAIL(SWIMM_E_FILE, "SWIMM: write error on '%s.desc'.", out_prefix); goto done; }
         fclose(fd); fd = NULL;
@@ -405,6 +424,21 @@ static int want_cmp(const void *a, const void *b)
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 
+/* title line `line` through the sidecar: [off[line], off[line + 1]) of .desc, '>' and the line end stripped */
+static char *title_at(int fd_desc, const uint64_t *off, uint64_t count, uint64_t desc_size, uint64_t line)
+{
+    const uint64_t b = off[line], e = line + 1 < count ? off[line + 1] : desc_size;
+    if (e < b || e > desc_size || e - b > ((uint64_t)1 << 26)) return NULL;
+    char *t = (char *)malloc(e - b + 1);
+    if (!t) return NULL;
+    if (e > b && pread(fd_desc, t, e - b, (off_t)b) != (ssize_t)(e - b)) { free(t); return NULL; }
+    size_t n = e - b;
+    while (n > 0 && (t[n - 1] == '\n' || t[n - 1] == '\r')) n--;
+    t[n] = 0;
+    if (n > 0 && t[0] == '>') memmove(t, t + 1, n);
+    return t;
+}
+
 int swimm_db_titles(const char *prefix, uint64_t count, const int64_t *idx, uint64_t n_idx, char **titles_out)
 {
     /* Only the wanted lines are copied: the file is mapped and walked with memchr up to the last wanted line (the
@@ -423,6 +457,31 @@ int swimm_db_titles(const char *prefix, uint64_t count, const int64_t *idx, uint
         w[i].line = idx[i];
         w[i].pos = i;
         titles_out[i] = NULL;
+    }
+    /* the sidecar <prefix>.didx (swimm_preprocess_db): N line offsets, valid only for a .desc of the size it names.  r titles are
+     * r positioned reads of a few dozen bytes -- at 3.5e7 titles the walk below reads the whole 3 GB file for a hit near its end. */
+    {
+        snprintf(name, sizeof name, "%s.didx", prefix);
+        const int fx = open(name, O_RDONLY);
+        if (fx >= 0) {
+            uint64_t hdr[3] = {0, 0, 0};
+            struct stat sx;
+            const int ok = fstat(fx, &sx) == 0 && pread(fx, hdr, sizeof hdr, 0) == (ssize_t)sizeof hdr && hdr[0] == SWIMM_DIDX_MAGIC && hdr[1] == count &&
+                           hdr[2] == (uint64_t)sb.st_size && (uint64_t)sx.st_size == sizeof hdr + count * sizeof(uint64_t);
+            const uint64_t *off = ok ? (const uint64_t *)mmap(NULL, (size_t)sx.st_size, PROT_READ, MAP_PRIVATE, fx, 0) : NULL;
+            close(fx);
+            if (ok && off != MAP_FAILED) {
+                int bad = 0;
+                for (uint64_t i = 0; i < n_idx && !bad; ++i) {
+                    titles_out[i] = title_at(fd, off + 3, count, (uint64_t)sb.st_size, (uint64_t)idx[i]);
+                    bad = titles_out[i] == NULL;
+                }
+                munmap((void *)off, (size_t)sx.st_size);
+                if (!bad) { free(w); close(fd); return SWIMM_OK; }
+                for (uint64_t i = 0; i < n_idx; ++i) { free(titles_out[i]); titles_out[i] = NULL; }      /* (damaged sidecar: walk the file) */
+            }
+        }
+        snprintf(name, sizeof name, "%s.desc", prefix);
     }
     qsort(w, n_idx, sizeof(want_t), want_cmp);
     const size_t len = (size_t)sb.st_size;

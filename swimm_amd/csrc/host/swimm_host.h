@@ -23,6 +23,7 @@ extern "C" {
 #define SWIMM_DUMMY_CODE 23   /* J, O, U            (DUMMY_ELEMENT recoded, sequences.h:17) */
 #define SWIMM_PAD_CODE 24     /* lane padding        (PREPROCESSED_DUMMY_ELEMENT, sequences.h:18) */
 #define SWIMM_SEQ_LEN_MULT 5  /* group length multiple (SEQ_LEN_MULT, sequences.h:19) */
+#define SWIMM_DIDX_MAGIC 0x584449444d495753ull   /* "SWIMDIDX": <prefix>.didx, line offsets of <prefix>.desc (this build's sidecar) */
 
 /* statuses (main.c exits with the reference's codes: 1 = memory, 2 = file, 3 = .desc) */
 #define SWIMM_OK 0
@@ -64,7 +65,9 @@ typedef struct {
 int swimm_db_load(const char *prefix, swimm_db *out);
 void swimm_db_free(swimm_db *db);
 /* N title lines of <prefix>.desc (load_database_headers, sequences.c:736-767); only the requested
- * indices are materialised: titles[i] = line idx[i], '>' stripped, newline stripped. */
+ * indices are materialised: titles[i] = line idx[i], '>' stripped, newline stripped.  With the sidecar <prefix>.didx that
+ * swimm_preprocess_db writes (uint64 offset of every line; ignored unless it names this .desc's size and count) each title is
+ * one positioned read; without it the file is walked up to the last wanted line. */
 int swimm_db_titles(const char *prefix, uint64_t count, const int64_t *idx, uint64_t n_idx, char **titles_out);
 
 /* ---- queries (load_query_sequences, sequences.c:223-423) ----

@@ -242,10 +242,13 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
     // costs is the order of the loops above: taller strips first.)
     std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.base < b.base; });
     double best_cost = -1;
+    const bool dbg = getenv("SWIMM_HIP_DEBUG_PLAN") != nullptr;
     for (const Cand &k : cands) {
         if (best_cost >= 0 && k.base >= best_cost * (1.0 - 1e-9)) break;
         const double imb = overlapped ? 1.0 : (rb ? lpt_imbalance(*rb, k.n_wg) : plan_imbalance(c, k.n_wg));
         const double cost = k.passes * (k.pass_base * imb + 150e-6);
+        if (dbg) fprintf(stderr, "swimm_hip: plan candidate m=%d: %d x %d rows, %d passes, %d workgroups: %.3f ms x makespan %.3f -> %.3f ms%s\n", m, k.W, k.T, k.passes, k.n_wg,
+                         k.base * 1e3, imb, cost * 1e3, room_for_lane_waves ? " (room for lane waves)" : "");
         if (best_cost < 0 || cost < best_cost * (1.0 - 1e-9)) {
             best_cost = cost;
             out->T = k.T; out->W = k.W; out->passes = k.passes; out->mpad = (uint32_t)(k.passes * k.W * k.T); out->est_s = cost;

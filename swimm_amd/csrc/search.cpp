@@ -349,6 +349,7 @@ struct SearchRun {
     Mode main_mode = Mode::F16;
     int f16_thr = 2048;                     // binary16 first tier: results >= this are re-run as packed int16 (f16_exact_below)
     bool lane_room = false, many_short = false, alternate = false;
+    bool cut_room = false;                  // outlier pairs exist: the queries of FEW passes leave the lane-systolic waves their registers too
     std::vector<uint8_t> use_sp;            // queries that run through the score-profile kernel (option "sp_threshold")
     std::vector<size_t> qcode_off;          // ... and where their padded residue codes start in d_qcodes
     uint32_t longest_cols = 0;
@@ -367,6 +368,18 @@ struct SearchRun {
     struct Unit { int stack; uint32_t q; };                  // an entry of a group-resident launch's query table: a stack, or a query
     std::map<std::pair<int, int>, std::vector<Unit>> by_shape;
     std::vector<std::vector<QueryPlan>> rqps;                // streaming, per-pass launches: a launch shape per (range, query)
+    // Streaming, ONE query that fits one pass: ONE pipeline launch over the whole database, started before the first byte has
+    // arrived.  Its item list holds every group in the order the parts travel, and the launch's workgroups pull from it as far
+    // as it has landed (sw_pipe_kernel, PipeParams::avail; the uploader publishes the count behind every part).  No ranges, no
+    // launch per range: a range of the longest sequences is a handful of 6 ms chains that the workgroups of the NEXT range's
+    // launch could only cover where a whole workgroup had ended -- here the same workgroups simply go on with what arrives.
+    bool one_list = false, one_list_launched = false;
+    bool stalled = false;                   // ... its workgroups gave up waiting for the database (drain): the caller searches the resident copy
+    QueryPlan one_list_qp;
+    uint32_t one_list_items = 0;
+    uint64_t one_list_chunks = 0;
+    std::vector<uint8_t> range_pp;          // streaming: ranges that run like a resident database (launch shapes per query, one launch per pass, tail kernels)
+    bool alternate_pp = false;              // ... whose multi-pass queries take turns on the two bulk streams
     size_t prof_elems = 0;
     int tail_lanes = 1;                     // lane-systolic tail launches per range: one per rows-per-lane class in use (informational)
     double stream_free[3] = {0, 0, 0};      // streaming, group-resident ranges: when each of the three streams is expected to have drained (s after t_begin)
@@ -376,6 +389,8 @@ struct SearchRun {
     {
         if (!streaming) return;
         if (c->up) c->up->finish(true);          // (an early return: the chunks not yet copied stay where they are)
+        if (one_list_launched && c->up && (c->up->failed || c->up->issued < up_order.size()))
+            (void)launch_publish_items(c->d_avail.p, kAvailAbort, c->stream_up);   // (its launch must not wait for what will not come)
         (void)hipDeviceSynchronize();
         release_stream_plans();
     }
@@ -390,7 +405,10 @@ struct SearchRun {
         if (c->up->wait_issued(n, &err)) return fail("%s", err.empty() ? "upload failed" : err.c_str());
         return 0;
     }
-    const QueryPlan &qp_of(size_t ri, uint32_t q) const { return rqps.empty() ? qps[q] : rqps[ri][q]; }
+    const QueryPlan &qp_of(size_t ri, uint32_t q) const { return ri < rqps.size() && !rqps[ri].empty() ? rqps[ri][q] : qps[q]; }
+    bool pp_range(size_t ri) const { return ri < range_pp.size() && range_pp[ri] != 0; }
+    bool res_of(size_t ri, uint32_t q) const { return in_batch[q] != 0 && !pp_range(ri); }      // the query runs in range ri's group-resident batch launch
+    int issue_one_list();
     int plan_of(size_t ri, uint32_t q, DbPlan **out);
     int plan_for(size_t ri, int T, int W, bool resident, bool whole_db, DbPlan **out);
     int build_stacks();
@@ -434,7 +452,7 @@ int SearchRun::plan_for(size_t ri, int T, int W, bool resident, bool whole_db, D
 
 int SearchRun::plan_of(size_t ri, uint32_t q, DbPlan **out)
 {
-    return plan_for(ri, qp_of(ri, q).T, qp_of(ri, q).W, in_batch[q] != 0, rotated[q] != 0 || use_sp[q] != 0 || qps[q].resident, out);
+    return plan_for(ri, qp_of(ri, q).T, qp_of(ri, q).W, res_of(ri, q), rotated[q] != 0 || use_sp[q] != 0 || res_of(ri, q), out);
 }
 
 // Which short queries share workgroups.  Candidates: the one-pass queries of up to 72 rows that run without a tail kernel
@@ -496,7 +514,6 @@ int SearchRun::begin(uint64_t *slots_out)
     if (!c->have_queries) return fail("swimm_hip_search: no queries set");
     if (c->groups.empty()) return fail("swimm_hip_search: no database chunk resident");
     CHECK_DEVICE(c);
-    pool_trim(c);                      // (buffers of a cleared database that the new chunks did not take)
     if (refresh_plans(c)) return 1;
     qn = qe - qb;
     dbg = getenv("SWIMM_HIP_DEBUG") != nullptr;
@@ -505,7 +522,10 @@ int SearchRun::begin(uint64_t *slots_out)
     qdisp = c->qdisp.data() + qb;
     S = (uint64_t)c->groups.size() * kGroupSeqs;
     *slots_out = S;
-
+    // (binary16 first tier: results below f16_exact_below(extend) are exact -- the pipeline kernel's column offsets take up to 127 of the
+    // 2048; with an extend penalty beyond 237 the tier would be exact below 1 100 only, and the int16 tier is the first)
+    main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 && f16_exact_below(c->extend_gap) >= 1100 ? Mode::F16 : Mode::PK16);
+    f16_thr = f16_exact_below(c->extend_gap);
     return 0;
 }
 
@@ -513,116 +533,157 @@ int SearchRun::layout_ranges()
 {
     // Chunks whose bytes are still on the host (option "lazy_upload"): this search streams them in -- chunk k+1 is
     // copied and tiled on the upload stream while chunk k is being aligned (X2 overlapped with compute,
-    // MICsearch.c:85-91) -- as a few ranges of consecutive chunks, each with work lists of its own.  Otherwise the whole resident
-    // database is one range with cached work lists.
+    // MICsearch.c:85-91).  Otherwise the whole resident database is one range with cached work lists.
     streaming = false;
     for (const ChunkRec &r : c->chunks) streaming = streaming || !r.uploaded;
     c->streaming_now = streaming;
-    if (streaming) {
+    c->batch_now = false;
+    if (!streaming) {
+        if (sync_lengths(c)) return 1;
+        ranges.push_back(whole_range(c));
+        return 0;
+    }
+    // FIRST the order in which the database travels, and the uploader (a thread of its own, Uploader) on its way: everything
+    // else this function and the next ones work out -- which parts form a range, launch shapes, profiles, buffers -- happens
+    // while the link is already busy.  (Round 3 laid the ranges out first: 10 ms on a 6.6 M-sequence database, 14 ms on 8.9 M,
+    // before the first byte moved.)
+    {
         uint64_t mb = 16, mn = 1, mg = 1, mo = 1;
         for (const ChunkRec &r : c->chunks) {
             if (r.uploaded) continue;
             mb = std::max<uint64_t>(mb, r.kind == 0 ? r.vD : r.code_bytes); mn = std::max<uint64_t>(mn, r.group_count);
             mg = std::max<uint64_t>(mg, r.n_groups); mo = std::max<uint64_t>(mo, r.off.size());
         }
-        // Consecutive chunks form a range, and every range is as large as it can be without the GPU running dry before
-        // it has arrived: the link delivers a chunk in bytes / 40 GB/s, the kernels consume it in (rows of all queries) x
-        // residues / 8 000 GCUPS -- 1.9x longer for one 375-row query, so the first range is one chunk, the second one or
-        // two, and the rest of the database follows in two or three large launches; a batch of long queries is
-        // compute-bound from the first chunk on and runs as two ranges.
-        // The end of the database with the LONGER sequences travels first: consecutive ranges run on alternating
-        // streams, so the few long chains a range ends with are covered by the next range's workgroups -- and the last
-        // range, which nothing covers, is then the one with the short sequences, whose launches end evenly.
-        c->stream_tail.clear();
-        c->stream_tail = pick_tail(c, whole_range(c));
-        const size_t nc = c->chunks.size();
-        const bool descending = nc > 1 && (double)c->chunks[nc - 1].cols / std::max<uint32_t>(1, c->chunks[nc - 1].n_groups) >
-                                              (double)c->chunks[0].cols / std::max<uint32_t>(1, c->chunks[0].n_groups);
-        // The chunk that travels first goes in parts -- 16 MiB, 32 MiB, the rest -- so that the first launch has its data
-        // after 0.4 ms instead of the 2 ms a whole 96 MiB chunk takes on the link (the head part is the chunk's end with the
-        // longest sequences when the database travels in descending order).
-        // ... and which chunk is that?  Not the one with the longest sequences: its groups are few (a 96 MiB chunk of 5 000-residue
-        // sequences is 26 groups per 16 MiB) and each is a chain of 15 ms, so the head launches would hold three streams with
-        // a few dozen workgroups while the chunks behind them wait for a stream (measured: 33.5 ms against 31.0 without parts).
-        // The chunk with the SHORTEST sequences goes first -- thousands of groups per part: the chip is full 0.4 ms after the
-        // call and its launches end as soon as their work is done -- then the database in descending order as before: the
-        // long chains start with the second chunk, 4 ms in, and the last range is still one of short sequences.
-        std::vector<size_t> chunk_order;
-        for (size_t i = 0; i < nc; ++i) chunk_order.push_back(descending ? nc - 1 - i : i);
-        const bool short_first = descending && nc >= 3 && qn <= 4;
-        if (short_first) { chunk_order.insert(chunk_order.begin(), chunk_order.back()); chunk_order.pop_back(); }
-        size_t n_part_ev = 0;
-        for (size_t i = 0; i < nc; ++i) {
-            const size_t ci = chunk_order[i];
-            const ChunkRec &r = c->chunks[ci];
-            const uint64_t bytes = r.kind == 0 ? r.vD : r.code_bytes;
-            bool ascending = true;
-            if (r.kind == 0 && !r.uploaded)
-                for (uint32_t v = 1; v < r.group_count; ++v) ascending = ascending && r.h_disp[v] >= r.h_disp[v - 1];
-            if (i == 0 && short_first && !r.uploaded && r.groups_uploaded == 0 && ascending && bytes >= ((uint64_t)56 << 20) && r.n_groups >= 16) {
-                const uint64_t heads[2] = {(uint64_t)16 << 20, (uint64_t)32 << 20};
-                uint32_t edge = descending ? r.n_groups : 0;      // the groups still to be dealt: [0, edge) or [edge, n)
-                for (int h = 0; h < 2; ++h) {
-                    uint64_t acc = 0;
-                    uint32_t cut = edge;
-                    if (descending) { while (cut > 8 && acc < heads[h]) { --cut; acc += (uint64_t)r.gcols[cut] * kGroupSeqs; } }
-                    else { while (cut + 8 < r.n_groups && acc < heads[h]) { acc += (uint64_t)r.gcols[cut] * kGroupSeqs; ++cut; } }
-                    while (c->part_ev.size() <= n_part_ev) {
-                        hipEvent_t e;
-                        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                        c->part_ev.push_back(e);
-                    }
-                    UploadPart pt; pt.chunk = ci; pt.g0 = descending ? cut : edge; pt.g1 = descending ? edge : cut; pt.ready = c->part_ev[n_part_ev++];
-                    up_order.push_back(pt);
-                    edge = cut;
-                }
-                UploadPart rest; rest.chunk = ci; rest.g0 = descending ? 0 : edge; rest.g1 = descending ? edge : r.n_groups; rest.ready = r.ready;
-                up_order.push_back(rest);
-            } else {
-                UploadPart pt; pt.chunk = ci; pt.g0 = 0; pt.g1 = r.n_groups; pt.ready = r.ready;
-                up_order.push_back(pt);
-            }
-        }
-        double rows = 0;
-        for (uint32_t q = 0; q < qn; ++q) rows += qm[q];
-        auto part_cols = [&](const UploadPart &pt) { uint64_t x = 0; const ChunkRec &r = c->chunks[pt.chunk]; for (uint32_t g = pt.g0; g < pt.g1; ++g) x += r.gcols[g]; return x; };
-        auto up_s = [&](const UploadPart &pt) { return (double)part_cols(pt) * kGroupSeqs / 40e9; };
-        auto dp_s = [&](const UploadPart &pt) { return 0.85 * rows * (double)part_cols(pt) * kGroupSeqs / 8000e9; };   // (rather too short: the GPU must not wait)
-        double t_up = 0, t_gpu = 0;
-        const size_t np = up_order.size();
-        for (size_t i = 0; i < np;) {
-            Range rg; rg.g0 = c->chunks[up_order[i].chunk].group0 + up_order[i].g0; rg.g1 = c->chunks[up_order[i].chunk].group0 + up_order[i].g1; rg.cols = 0;
-            const size_t first = i;
-            double work = 0;
-            do {
-                const UploadPart &pt = up_order[i];
-                const ChunkRec &r = c->chunks[pt.chunk];
-                rg.g0 = std::min(rg.g0, r.group0 + pt.g0); rg.g1 = std::max(rg.g1, r.group0 + pt.g1); rg.cols += part_cols(pt);
-                t_up += up_s(pt); work += dp_s(pt);
-                ++i;
-                if (i < np) {                              // (a range is a run of consecutive device groups)
-                    const uint32_t n0 = c->chunks[up_order[i].chunk].group0 + up_order[i].g0, n1 = c->chunks[up_order[i].chunk].group0 + up_order[i].g1;
-                    if (n0 != rg.g1 && n1 != rg.g0) break;
-                }
-            } while (i < np && t_up + up_s(up_order[i]) <= t_gpu);
-            t_gpu = std::max(t_gpu, t_up) + work;
-            ranges.push_back(rg);
-            range_chunks.push_back({first, i});
-        }
         // the upload scratch grows now, not between two chunks (growing frees the old buffer)
         HIP_TRY(c->up_b.reserve(mb)); HIP_TRY(c->up_n.reserve(mn)); HIP_TRY(c->up_disp.reserve(mn));
         HIP_TRY(c->up_gcols.reserve(mg)); HIP_TRY(c->up_goff.reserve(mg)); HIP_TRY(c->up_off.reserve(mo));
+    }
+    // The end of the database with the LONGER sequences travels first: the few long chains it holds start early and are
+    // covered by everything that follows, and what arrives last -- what nothing covers -- is short sequences, whose work ends evenly.
+    const size_t nc = c->chunks.size();
+    const bool descending = nc > 1 && (double)c->chunks[nc - 1].cols / std::max<uint32_t>(1, c->chunks[nc - 1].n_groups) >
+                                          (double)c->chunks[0].cols / std::max<uint32_t>(1, c->chunks[0].n_groups);
+    // The chunk that travels first goes in parts -- 16 MiB, 32 MiB, the rest -- so that the first launch has its data
+    // after 0.4 ms instead of the 2 ms a whole 96 MiB chunk takes on the link.  And which chunk is that?  Not the one with the
+    // longest sequences: its groups are few (a 96 MiB chunk of 5 000-residue sequences is 26 groups per 16 MiB) and each is a
+    // chain of many milliseconds (measured in round 3: 33.5 ms against 31.0 without parts).  The chunk with the SHORTEST
+    // sequences goes first -- thousands of groups per part: the chip is full 0.4 ms after the call -- then the database in
+    // descending order: the long chains start with the second chunk, 4 ms in.
+    std::vector<size_t> chunk_order;
+    for (size_t i = 0; i < nc; ++i) chunk_order.push_back(descending ? nc - 1 - i : i);
+    const bool short_first = descending && nc >= 3 && qn <= 4;
+    if (short_first) { chunk_order.insert(chunk_order.begin(), chunk_order.back()); chunk_order.pop_back(); }
+    size_t n_part_ev = 0;
+    for (size_t i = 0; i < nc; ++i) {
+        const size_t ci = chunk_order[i];
+        const ChunkRec &r = c->chunks[ci];
+        const uint64_t bytes = r.kind == 0 ? r.vD : r.code_bytes;
+        bool ascending = true;
+        if (r.kind == 0 && !r.uploaded)
+            for (uint32_t v = 1; v < r.group_count; ++v) ascending = ascending && r.h_disp[v] >= r.h_disp[v - 1];
+        if (i == 0 && short_first && !r.uploaded && r.groups_uploaded == 0 && ascending && bytes >= ((uint64_t)56 << 20) && r.n_groups >= 16) {
+            const uint64_t heads[2] = {(uint64_t)16 << 20, (uint64_t)32 << 20};
+            uint32_t edge = descending ? r.n_groups : 0;      // the groups still to be dealt: [0, edge) or [edge, n)
+            for (int h = 0; h < 2; ++h) {
+                uint64_t acc = 0;
+                uint32_t cut = edge;
+                if (descending) { while (cut > 8 && acc < heads[h]) { --cut; acc += (uint64_t)r.gcols[cut] * kGroupSeqs; } }
+                else { while (cut + 8 < r.n_groups && acc < heads[h]) { acc += (uint64_t)r.gcols[cut] * kGroupSeqs; ++cut; } }
+                while (c->part_ev.size() <= n_part_ev) {
+                    hipEvent_t e;
+                    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    c->part_ev.push_back(e);
+                }
+                UploadPart pt; pt.chunk = ci; pt.g0 = descending ? cut : edge; pt.g1 = descending ? edge : cut; pt.ready = c->part_ev[n_part_ev++];
+                up_order.push_back(pt);
+                edge = cut;
+            }
+            UploadPart rest; rest.chunk = ci; rest.g0 = descending ? 0 : edge; rest.g1 = descending ? edge : r.n_groups; rest.ready = r.ready;
+            up_order.push_back(rest);
+        } else {
+            UploadPart pt; pt.chunk = ci; pt.g0 = 0; pt.g1 = r.n_groups; pt.ready = r.ready;
+            up_order.push_back(pt);
+        }
+    }
+    const size_t np = up_order.size();
+    // ONE query that one pass of one workgroup shape holds: one launch over one item list that grows as the parts land.
+    one_list = false;
+    QueryPlan one_qp{};
+    if (qn == 1 && c->opt_dynamic && main_mode == Mode::F16 && c->opt_resident != 1 && (int)qm[0] < c->opt_sp_threshold && c->groups.size() < 0x7FFFFFF0ull &&
+        choose_plan(c, main_mode, qm[0], false, true, &one_qp) == 0) {
+        one_list = true;
+        one_list_qp = one_qp;
+        std::vector<Item> items;
+        items.reserve(c->groups.size());
+        std::vector<uint32_t> order;
+        one_list_chunks = 0;
+        for (UploadPart &pt : up_order) {
+            const ChunkRec &r = c->chunks[pt.chunk];
+            order.resize(pt.g1 - pt.g0);
+            for (uint32_t g = pt.g0; g < pt.g1; ++g) order[g - pt.g0] = r.group0 + g;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->groups[a].ncols > c->groups[b].ncols; });    // longest first within what arrives together
+            for (uint32_t g : order) {
+                const GroupDesc &gd = c->groups[g];
+                Item it{}; it.db = gd.db; it.ncols = gd.ncols; it.seq0 = gd.seq0; it.half = 0; it.out_slot = 0; it.bnd_off = 0;
+                items.push_back(it);
+                one_list_chunks += gd.ncols / kChunkCols;
+            }
+            pt.publish = (uint32_t)items.size();
+        }
+        one_list_items = (uint32_t)items.size();
+        HIP_TRY(c->d_stream_items.reserve(items.size()));
+        HIP_TRY(c->d_avail.reserve(4));
+        // the count starts at zero -- on the UPLOAD stream, ahead of everything the uploader will put there
+        HIP_TRY(hipMemsetAsync(c->d_avail.p, 0, 4 * sizeof(uint32_t), c->stream_up));
+        if (!c->ev_avail) HIP_TRY(hipEventCreateWithFlags(&c->ev_avail, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_avail, c->stream_up));          // (the launch must not read the count the previous search left there)
+        if (list_copy(c, c->d_stream_items.p, items.data(), items.size() * sizeof(Item))) return 1;     // (waited for before the launch, issue())
     } else {
-        if (sync_lengths(c)) return 1;
+        (void)hipGetLastError();
+        g_err.clear();
+    }
+    if (ensure_uploader(c)) return 1;
+    c->up->post(up_order);
+    if (dbg) fprintf(stderr, "swimm_hip: upload order laid out (%zu parts%s), uploader started %.3f ms after the call began\n", np, one_list ? ", one item list" : "", (now_s() - t_begin) * 1e3);
+    if (one_list) {
         ranges.push_back(whole_range(c));
+        range_chunks.push_back({0, np});
+        stream_plans.resize(1);
+        return 0;
     }
-    // The uploader (Uploader, above) walks the chunk list from the first moment of the search while this thread plans,
-    // builds work lists and launches.
-    if (streaming) {
-        if (ensure_uploader(c)) return 1;
-        c->up->post(up_order);
+    // Consecutive parts form a range, and every range is as large as it can be without the GPU running dry before
+    // it has arrived: the link delivers a chunk in bytes / 40 GB/s, the kernels consume it in (rows of all queries) x
+    // residues / 8 000 GCUPS; a batch of long queries is compute-bound from the first chunk on and runs as two ranges.
+    c->stream_tail.clear();
+    c->stream_tail = pick_tail(c, whole_range(c));
+    double rows = 0;
+    for (uint32_t q = 0; q < qn; ++q) rows += qm[q];
+    auto part_cols = [&](const UploadPart &pt) { uint64_t x = 0; const ChunkRec &r = c->chunks[pt.chunk]; for (uint32_t g = pt.g0; g < pt.g1; ++g) x += r.gcols[g]; return x; };
+    std::vector<uint64_t> pcols(np);
+    for (size_t i = 0; i < np; ++i) pcols[i] = part_cols(up_order[i]);
+    auto up_s = [&](size_t i) { return (double)pcols[i] * kGroupSeqs / 40e9; };
+    auto dp_s = [&](size_t i) { return 0.85 * rows * (double)pcols[i] * kGroupSeqs / 8000e9; };   // (rather too short: the GPU must not wait)
+    double t_up = 0, t_gpu = 0;
+    for (size_t i = 0; i < np;) {
+        Range rg; rg.g0 = c->chunks[up_order[i].chunk].group0 + up_order[i].g0; rg.g1 = c->chunks[up_order[i].chunk].group0 + up_order[i].g1; rg.cols = 0;
+        const size_t first = i;
+        double work = 0;
+        do {
+            const UploadPart &pt = up_order[i];
+            const ChunkRec &r = c->chunks[pt.chunk];
+            rg.g0 = std::min(rg.g0, r.group0 + pt.g0); rg.g1 = std::max(rg.g1, r.group0 + pt.g1); rg.cols += pcols[i];
+            t_up += up_s(i); work += dp_s(i);
+            ++i;
+            if (i < np) {                              // (a range is a run of consecutive device groups)
+                const uint32_t n0 = c->chunks[up_order[i].chunk].group0 + up_order[i].g0, n1 = c->chunks[up_order[i].chunk].group0 + up_order[i].g1;
+                if (n0 != rg.g1 && n1 != rg.g0) break;
+            }
+        } while (i < np && t_up + up_s(i) <= t_gpu);
+        t_gpu = std::max(t_gpu, t_up) + work;
+        ranges.push_back(rg);
+        range_chunks.push_back({first, i});
     }
-    stream_plans.resize(streaming ? ranges.size() : 0);
+    stream_plans.resize(ranges.size());
     return 0;
 }
 
@@ -631,10 +692,21 @@ int SearchRun::plan_queries()
     // query profiles prof[q][d][row] = submat[query[row]*32 + d] (queryProfiles, MICsearch.c:34-36,
     // transposed so that consecutive query rows are contiguous for one residue code); rows past the
     // query's end are zero, like the reference's dummy row 23
-    // (binary16 first tier: results below f16_exact_below(extend) are exact -- the pipeline kernel's column offsets take up to 127 of the
-    // 2048; with an extend penalty beyond 237 the tier would be exact below 1 100 only, and the int16 tier is the first)
-    main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 && f16_exact_below(c->extend_gap) >= 1100 ? Mode::F16 : Mode::PK16);
-    f16_thr = f16_exact_below(c->extend_gap);
+    range_pp.assign(ranges.size(), 0);
+    alternate_pp = false;
+    if (one_list) {          // one query, one pass, one launch over the whole database as it lands (layout_ranges)
+        qps.assign(1, one_list_qp);
+        rotated.assign(1, 0); use_sp.assign(1, 0); in_batch.assign(1, 0); stack_of.assign(1, -1);
+        stacks.clear();
+        lane_room = cut_room = many_short = alternate = false;
+        c->batch_now = false;
+        const uint32_t lane_rows = (uint32_t)((qm[0] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));     // (the promotion re-runs read the same profile)
+        qps[0].mpad = std::max(qps[0].mpad, lane_rows);
+        qps[0].prof_off = 0;
+        prof_elems = (size_t)kCodes * qps[0].mpad;
+        if (dbg) fprintf(stderr, "swimm_hip: query 0 m=%u -> one launch of %d x %d rows over the %u groups as they land\n", qm[0], qps[0].W, qps[0].T, one_list_items);
+        return 0;
+    }
     // a database with a long-sequence tail is searched with launch shapes that leave room for lane-systolic waves
     lane_room = false;
     longest_cols = 0;
@@ -643,7 +715,12 @@ int SearchRun::plan_queries()
         lane_room = c->opt_tail_mode == 1 || (double)longest_cols > c->opt_tail_frac * 0.01 * (double)c->total_cols / c->num_cu;
     if (c->opt_tail_mode != 2 && main_mode != Mode::I32) {          // outlier pairs run through the lane-systolic kernel as well
         ensure_cuts(c);
-        for (size_t g = 0; g < c->cut_lane.size() && !lane_room; ++g) lane_room = c->cut_lane[g] < 64;
+        // Outlier pairs are a handful of lane-systolic items.  A query of many passes needs no room kept for them: its launches end
+        // pass after pass and the lane waves move in at the first boundary, their chain running beside the passes that follow
+        // (c4 at 19 % of its size: 9 990 GCUPS with the 4 x 36 shape that keeps the room, 10 540 with 4 x 32 that does not).  A
+        // query of one or two passes would see that chain only start when its own kernels end: those keep the room.
+        cut_room = false;
+        for (size_t g = 0; g < c->cut_lane.size() && !cut_room; ++g) cut_room = c->cut_lane[g] < 64;
     }
     if (dbg) fprintf(stderr, "swimm_hip: ranges laid out, uploader started %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     qps.assign(qn, QueryPlan{});
@@ -746,13 +823,27 @@ int SearchRun::plan_queries()
     if (build_stacks()) return 1;
     c->batch_now = false;
     const bool any_batch = batch_formed;
+    // A search that is long beside its upload (many queries, or a long one): the link has delivered everything while the first
+    // small ranges were aligned, and the LAST range is most of the database.  That range runs as the resident database would --
+    // a launch shape per query, one launch per pass, tail kernels, two streams in alternation -- instead of joining the
+    // group-resident batch launches of the ranges before it: on a database of dozens of groups per workgroup the per-pass
+    // launches are the faster ones (c5 at a quarter of its size: 7 195 ms resident, 7 420 ms as one batch launch per range).
+    if (streaming && batch_formed && ranges.size() >= 2) {
+        const Range &last = ranges.back();
+        if (2 * last.cols >= c->total_cols && (uint64_t)(last.g1 - last.g0) >= 8ull * (uint64_t)n_workgroups(c, 4)) range_pp.back() = 1;
+    }
     std::vector<BulkCols> rbulk;
-    if (streaming && !batch_formed && ranges.size() > 1) {
-        rqps.assign(ranges.size(), std::vector<QueryPlan>(qn));
+    if (streaming && ranges.size() > 1 && (!batch_formed || range_pp.back())) {
+        rqps.assign(ranges.size(), std::vector<QueryPlan>());
         rbulk.resize(ranges.size());
-        for (size_t ri = 0; ri < ranges.size(); ++ri) bulk_cols_of(c, ranges[ri], rbulk[ri]);
+        for (size_t ri = 0; ri < ranges.size(); ++ri) {
+            if (batch_formed && !range_pp[ri]) continue;
+            rqps[ri].resize(qn);
+            bulk_cols_of(c, ranges[ri], rbulk[ri]);
+        }
     }
     for (uint32_t q = 0; q < qn; ++q) {
+        const bool room = lane_room || (cut_room && qm[q] <= 1024);
         if (stack_of[q] >= 0) {                            // the query runs as a member of a stack: the stack's shape, one pass
             const Stack &st = stacks[stack_of[q]];
             qps[q].T = st.T; qps[q].W = st.W; qps[q].passes = 1; qps[q].mpad = 0;
@@ -760,15 +851,17 @@ int SearchRun::plan_queries()
         if (use_sp[q]) {                                   // the score-profile kernel: one wave of 32 rows per workgroup
             qps[q].T = kSpRows; qps[q].W = 1; qps[q].passes = (int)((qm[q] + kSpRows - 1) / kSpRows); qps[q].mpad = 0; qps[q].sp = true;
         } else
-        if (!in_batch[q] && !rotated[q] && choose_plan(c, main_mode, qm[q], lane_room, false, &qps[q])) return 1;   // (a batch's shapes are chosen above)
+        if (!in_batch[q] && !rotated[q] && choose_plan(c, main_mode, qm[q], room, false, &qps[q])) return 1;   // (a batch's shapes are chosen above)
         if (dbg)
-            fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)lane_room);
+            fprintf(stderr, "swimm_hip: query %u m=%u -> T=%d W=%d passes=%d (lane_room=%d)\n", q, qm[q], qps[q].T, qps[q].W, qps[q].passes, (int)room);
         // A database that is streaming in, per-pass launches: every range gets the launch shape that suits ITS groups -- the
         // range with the longest sequences is small beside the chip (a few long chains over hundreds of workgroups), and
         // fewer, taller workgroups finish it sooner than the shape that is best for the database as a whole.
         if (!rqps.empty())
             for (size_t ri = 0; ri < ranges.size(); ++ri) {
-                if (choose_plan(c, main_mode, qm[q], lane_room, false, &rqps[ri][q], &ranges[ri], &rbulk[ri])) return 1;
+                if (rqps[ri].empty()) continue;
+                if (use_sp[q]) { rqps[ri][q] = qps[q]; continue; }
+                if (choose_plan(c, main_mode, qm[q], room, false, &rqps[ri][q], &ranges[ri], &rbulk[ri])) return 1;
                 qps[q].mpad = std::max(qps[q].mpad, rqps[ri][q].mpad);
                 if (dbg) fprintf(stderr, "swimm_hip:   range %zu: T=%d W=%d passes=%d\n", ri, rqps[ri][q].T, rqps[ri][q].W, rqps[ri][q].passes);
             }
@@ -790,6 +883,13 @@ int SearchRun::plan_queries()
     uint32_t n_multi = 0;
     for (uint32_t q = 0; q < qn; ++q) n_multi += !rotated[q] && !in_batch[q] && !use_sp[q] && qps[q].passes > 1;
     alternate = n_multi >= 2 && !streaming;
+    if (!range_pp.empty() && range_pp.back()) {
+        uint32_t n_multi_pp = 0;
+        for (uint32_t q = 0; q < qn; ++q) n_multi_pp += !use_sp[q] && stack_of[q] < 0 && rqps.back()[q].passes > 1;
+        alternate_pp = n_multi_pp >= 2;
+        if (dbg) fprintf(stderr, "swimm_hip: the last range (%u groups, %llu columns) runs like a resident database: one launch per pass%s\n", ranges.back().g1 - ranges.back().g0,
+                         (unsigned long long)ranges.back().cols, alternate_pp ? ", queries alternating on two streams" : "");
+    }
     c->batch_now = any_batch;
     return 0;
 }
@@ -817,7 +917,7 @@ int SearchRun::upload_profiles()
     c->last_plans.resize(c->qm.size());
     for (uint32_t q = 0; q < qn; ++q) { qps[q].mode = main_mode; qps[q].dynamic = c->opt_dynamic != 0; qps[q].resident = in_batch[q] != 0; c->last_plans[qb + q] = qps[q]; }
     for (auto &rv : rqps)
-        for (uint32_t q = 0; q < qn; ++q) {
+        for (uint32_t q = 0; q < qn && !rv.empty(); ++q) {
             rv[q].mpad = qps[q].mpad; rv[q].prof_off = qps[q].prof_off;      // one profile per query, padded for the tallest plan
             rv[q].mode = main_mode; rv[q].dynamic = qps[q].dynamic; rv[q].resident = false;
         }
@@ -866,7 +966,9 @@ int SearchRun::size_buffers()
         size_t tail_cols = 0, tail_items = 0, launch_total = 16;
         int max_passes = 1;
         for (uint32_t q = 0; q < qn; ++q) max_passes = std::max(max_passes, (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
-        if (streaming) {
+        if (one_list) {
+            // (one launch, no boundary rows, no tail: nothing to size but the launch cursor and the promotion ladder's scratch below)
+        } else if (streaming) {
             // a range's work lists are built when its turn comes (the GPU is busy with the range before it by then):
             // size the shared buffers from the geometry alone
             const uint64_t budget = bnd_budget_cols(c);
@@ -888,9 +990,9 @@ int SearchRun::size_buffers()
                     const QueryPlan &qp = qp_of(ri, q);
                     if (qp.passes <= 1) { launch_total += 2; continue; }
                     int per_cu = 1;
-                    if (wgs_per_cu(c, main_mode, qp.T, qp.W, in_batch[q] != 0, &per_cu)) return 1;
+                    if (wgs_per_cu(c, main_mode, qp.T, qp.W, res_of(ri, q), &per_cu)) return 1;
                     const uint64_t cols = ranges[ri].cols * (main_mode == Mode::I32 ? 2 : 1);
-                    if (qps[q].resident) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_all * 64);   // (a batch takes every group)
+                    if (res_of(ri, q)) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_all * 64);   // (a batch takes every group)
                     // (only the dynamic queue's list is cut into runs that fit the budget: the static partition takes the range whole)
                     else need_bnd = std::max<uint64_t>(need_bnd, (c->opt_dynamic ? std::min<uint64_t>(cols, std::max<uint64_t>(budget, longest_main)) : cols) * 64);
                     // (runs of the boundary buffer: the greedy cut closes a run when the next item would overflow it, so two
@@ -928,7 +1030,7 @@ int SearchRun::size_buffers()
         }
         if (dbg) fprintf(stderr, "swimm_hip: buffer sizes known %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
         HIP_TRY(c->d_bnd.reserve(need_bnd));
-        if (alternate || c->batch_now || streaming) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
+        if (alternate || c->batch_now || (streaming && !one_list)) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
         if (c->batch_now && streaming) HIP_TRY(c->d_bnd_c.reserve(need_bnd));
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
@@ -1016,9 +1118,13 @@ int SearchRun::issue()
         if (list_copy(c, c->d_qdesc.p, qd_host.data(), qd_host.size() * sizeof(QDesc)) ||
             list_copy(c, c->d_wave_out.p, wave_host.data(), wave_host.size() * sizeof(uint32_t)) || list_sync(c)) return 1;
     }
-    if (streaming)          // the first range's work lists need its geometry only: ready before its bytes are
+    if (streaming && !one_list)          // the first range's work lists need its geometry only: ready before its bytes are
         for (uint32_t q = 0; q < qn; ++q) { DbPlan *dp = nullptr; if (plan_of(0, q, &dp)) return 1; }
     for (size_t ri = 0; ri < ranges.size(); ++ri) {
+        if (one_list) {                  // ONE launch over the whole list, now -- it follows the upload by itself
+            if (issue_one_list()) return 1;
+            break;
+        }
         if (streaming) {
             if (wait_uploaded(range_chunks[ri].second)) return 1;
             const UploadPart &last = up_order[range_chunks[ri].second - 1];   // the upload stream is in order: its last part's event covers the range
@@ -1036,7 +1142,8 @@ int SearchRun::issue()
             const LaneList *ll = nullptr;
             for (uint32_t k = 0; k < qn; ++k) {
                 const uint32_t q = qn - 1 - k;
-                if (stack_of[q] >= 0 || qps[q].resident || rotated[q] || use_sp[q]) continue;      // (every group through the pipeline kernel)
+                if ((stack_of[q] >= 0 && !pp_range(ri)) || res_of(ri, q) || rotated[q] || use_sp[q]) continue;      // (every group through the pipeline kernel)
+                if (stack_of[q] >= 0) continue;            // (a stack's members run whole, below, also in a range that runs per pass)
                 DbPlan *dp = nullptr;
                 if (plan_of(ri, q, &dp)) return 1;
                 if (dp->tail.n == 0) continue;
@@ -1061,7 +1168,7 @@ int SearchRun::issue()
         // the bulk kernels of the shorter queries instead of running alone at the end.
         for (uint32_t k = 0; k < qn; ++k) {
             const uint32_t q = qn - 1 - k;                 // queries arrive sorted by ascending length
-            if (stack_of[q] >= 0 || qps[q].resident) continue;     // its stack / its batch launch takes it, below
+            if (stack_of[q] >= 0 || res_of(ri, q)) continue;     // its stack / its batch launch takes it, below
             DbPlan *dp = nullptr;
             if (plan_of(ri, q, &dp)) return 1;
             int32_t *row = c->d_scores.p + (size_t)q * S;
@@ -1099,16 +1206,16 @@ int SearchRun::issue()
             // and a launch that runs alone ends with a few workgroups holding the chip -- c3's last eight queries: 26 ms at 5 900 GCUPS)
             // Each query goes to the stream with less work so far (padded rows), longest first: strict turns left one stream
             // 6 % more rows on c3 and the other idle for the last 60 ms.
-            if (alternate && !rotated[q] && !qps[q].resident && !(many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows)) {
+            if ((alternate || (alternate_pp && pp_range(ri))) && !rotated[q] && !res_of(ri, q) && !(many_short && qps[q].passes == 1 && qm[q] <= 64 * kLaneRows)) {
                 const int pick = alt_rows[1] < alt_rows[0] ? 1 : 0;
-                alt_rows[pick] += (double)qps[q].passes * qps[q].W * qps[q].T;
+                alt_rows[pick] += (double)qp_of(ri, q).passes * qp_of(ri, q).W * qp_of(ri, q).T;
                 if (pick == 1) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }
             }
-            if (streaming && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
+            if (streaming && !pp_range(ri) && (ri & 1)) { bulk_stream = c->stream_b; bnd = &c->d_bnd_b; }     // consecutive ranges overlap
             if (dbg)
                 fprintf(stderr, "swimm_hip: query %u (%u rows, %d passes of %d x %d): bulk on %s\n", q, qm[q], qp_of(ri, q).passes, qp_of(ri, q).W, qp_of(ri, q).T,
                         bulk_stream == c->stream ? "stream A" : bulk_stream == c->stream_b ? "stream B" : "the tail stream");
-            if (dp->have_main && run_passes(c, main_mode, qp_of(ri, q), dp->main, row, bulk_stream, !streaming && !alternate, *bnd)) return 1;
+            if (dp->have_main && run_passes(c, main_mode, qp_of(ri, q), dp->main, row, bulk_stream, pp_range(ri) ? !alternate_pp : !streaming && !alternate, *bnd)) return 1;
             HIP_TRY(hipEventRecord(c->ev_query[2 * q], bulk_stream));
             if (dp->tail.n == 0 || rotated[q]) HIP_TRY(hipEventRecord(c->ev_query[2 * q + 1], bulk_stream));      // (no tail launch recorded it above)
         }
@@ -1116,7 +1223,7 @@ int SearchRun::issue()
         // the three streams in turn like the single short queries above.
         for (size_t si = 0; si < stacks.size(); ++si) {
             const Stack &stk = stacks[si];
-            if (stk.resident) continue;
+            if (stk.resident && !pp_range(ri)) continue;
             QueryPlan sp{};
             sp.T = stk.T; sp.W = stk.W; sp.passes = 1; sp.mpad = stk.rows; sp.prof_off = stk.prof_off; sp.mode = main_mode; sp.dynamic = true; sp.resident = false;
             sp.stack = true; sp.seam_mask = stk.seam_mask; sp.wave_tab = stk.wave_tab;
@@ -1139,6 +1246,7 @@ int SearchRun::issue()
         {
             uint32_t bi = 0;
             for (auto &kv : by_shape) {
+                if (pp_range(ri)) break;                   // (this range runs one launch per pass, above)
                 const size_t off = qdesc_off[kv.first];
                 const int T = kv.first.first, W = kv.first.second;
                 const uint32_t nqb = (uint32_t)kv.second.size();
@@ -1199,6 +1307,53 @@ int SearchRun::issue()
         c->up->finish(false);
         if (sync_lengths(c)) return 1;             // the promotion re-runs stop every alignment at its true length
     }
+    return 0;
+}
+
+// The one launch of a streaming search for one query (layout_ranges): every group of the database through the pipeline kernel,
+// in the order the parts travel, the workgroups pulling from the list as far as the uploader has published it.
+int SearchRun::issue_one_list()
+{
+    const QueryPlan &qp = qps[0];
+    // Workgroups: what the chip holds of THIS instantiation -- less a few CUs' worth.  These workgroups stay until the list is
+    // exhausted, waiting (registers and all) whenever the link is behind; the tiling kernels of the parts still to come must
+    // find a place to run meanwhile, whatever the pipeline kernel's register count leaves free on a CU.
+    int regs = 0;
+    HIP_TRY(grow_kernel_attributes(qp.T, &regs));
+    const int per_cu = std::max(1, std::min(4 * regs_to_waves_per_simd(regs) / qp.W, (int)(163840 / pipe_lds_bytes(main_mode, qp.T, qp.W, false))));
+    const int kTilingCUs = getenv("SWIMM_HIP_EXP_TILING_CUS") ? atoi(getenv("SWIMM_HIP_EXP_TILING_CUS")) : 8;
+    const int cus = c->num_cu > 4 * kTilingCUs ? c->num_cu - kTilingCUs : c->num_cu;
+    int n_wg = cus * per_cu;
+    if (c->opt_wg_limit > 0) n_wg = std::min(n_wg, c->opt_wg_limit);
+    n_wg = (int)std::min<uint32_t>((uint32_t)n_wg, one_list_items);
+    if (list_sync(c)) return 1;                                   // the item list has arrived (copied while the plans were made)
+    if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
+    PipeParams p{};
+    fill_common(c, qp, p, nullptr);
+    p.items = c->d_stream_items.p;
+    p.n_items = one_list_items;
+    p.avail = c->d_avail.p;
+    p.max_steps = (uint32_t)std::min<uint64_t>(one_list_chunks + kMaxWaves + 1, 0x3ffffff0u);
+    p.queue = c->d_queue.p + c->queue_next++;
+    p.r0 = 0;
+    p.first_pass = 1; p.last_pass = 1;
+    p.out = c->d_scores.p;
+    p.err = c->d_err.p;
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_avail, 0));
+    if (timed_launch(c, main_mode, qp.T, qp.W, n_wg, p, c->stream)) return 1;
+    one_list_launched = true;
+    c->launches++;
+    c->cells += one_list_chunks * kChunkCols * (uint64_t)(qp.W * qp.T) * 128;
+    HIP_TRY(hipEventRecord(c->ev_query[0], c->stream));
+    HIP_TRY(hipEventRecord(c->ev_query[1], c->stream));
+    if (dbg) fprintf(stderr, "swimm_hip: one launch of %d workgroups (%d x %d rows) over %u items issued %.3f ms after the call began\n", n_wg, qp.W, qp.T, one_list_items, (now_s() - t_begin) * 1e3);
+    // the launch is on its way; now the host waits for the uploader (a failed upload must not leave the launch waiting)
+    if (wait_uploaded(up_order.size())) {
+        const std::string msg = g_err;
+        (void)launch_publish_items(c->d_avail.p, kAvailAbort, c->stream_up);
+        return fail("%s", msg.c_str());
+    }
+    if (dbg) fprintf(stderr, "swimm_hip: host copies done %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     return 0;
 }
 
@@ -1378,15 +1533,36 @@ int SearchRun::drain()
                 streaming ? " (streaming upload)" : "", t_sized - t_begin, t_issued - t_sized, now_s() - t_issued, ms * 1e-3);
     uint32_t werr = 0;
     HIP_TRY(hipMemcpy(&werr, c->d_err.p, sizeof werr, hipMemcpyDeviceToHost));
+    if (dbg && one_list_launched) {
+        uint32_t av[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(av, c->d_avail.p, sizeof av, hipMemcpyDeviceToHost);
+        fprintf(stderr, "swimm_hip: the item list's published count at the end: %u of %u; watchdog word %u\n", av[0], one_list_items, werr);
+    }
+    if (werr == 16u && one_list_launched) {     // (the one launch over the landing list ran out of patience: not wrong scores, missing ones)
+        stalled = true;
+        return fail("the streaming launch stopped waiting for the database");
+    }
     if (werr) return fail("pipeline watchdog expired (code %u): results discarded", werr);
     if (streaming) { release_plans(c); c->groups_dirty = true; }   // (the cached lists of the resident database are built on the next search)
+    pool_trim(c);                      // (buffers of a cleared database that the new chunks did not take: freed now, not at the start of a search)
     return 0;
 }
 
 int search_device(swimm_hip_ctx *c, uint32_t qb, uint32_t qe, uint64_t *slots_out)
 {
-    SearchRun run(c, qb, qe);
-    return run.run(slots_out);
+    {
+        SearchRun run(c, qb, qe);
+        if (run.run(slots_out) == 0) return 0;
+        if (!run.stalled) return 1;
+    }
+    // The one launch of a streaming search gave up waiting for its data (sw_kernels.hip, wait_landed) and has ended; the
+    // uploader has handed every part to the device meanwhile.  Once more, on the database that is resident now.
+    if (getenv("SWIMM_HIP_DEBUG")) fprintf(stderr, "swimm_hip: the streaming launch stalled; searching the resident database instead\n");
+    HIP_TRY(hipDeviceSynchronize());
+    for (const ChunkRec &r : c->chunks)
+        if (!r.uploaded) return fail("the streaming launch stopped waiting for the database and the upload did not complete");
+    SearchRun again(c, qb, qe);
+    return again.run(slots_out);
 }
 
 

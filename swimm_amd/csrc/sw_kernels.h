@@ -59,6 +59,9 @@ struct PipeParams {
     uint32_t *queue;            // dynamic queue: cursor into items[] (sorted longest first), zeroed before the launch;
                                 // nullptr selects the static partition
     uint32_t n_items;           // dynamic queue: length of items[]
+    const uint32_t *avail;      // dynamic queue of a database that is still streaming in (one launch over the whole list, in upload order): how
+                                // many items of the list have landed so far, published behind every part's tiling kernel (publish_items_kernel);
+                                // wave 0 waits for an item's turn before it hands the item out.  nullptr: everything is resident
     uint32_t max_steps;         // dynamic queue: upper bound of a workgroup's loop (all chunks of the list + waves)
     const int16_t *prof;        // query profile prof[d * prof_stride + row]
     uint32_t prof_stride;       // rows allocated per code (>= passes * W * T)
@@ -128,7 +131,7 @@ struct LaneParams {
     int goe, ge;
     uint32_t *err;              // watchdog word
 };
-size_t lane_lds_bytes(int rows_per_lane);
+size_t lane_lds_bytes(Mode mode, int rows_per_lane);
 // rows_per_lane: kLaneRows (any query), or 4 / 2 for a one-pass launch of a query of <= 256 / <= 128 rows
 hipError_t launch_lane(Mode mode, int rows_per_lane, int n_wg, const LaneParams &p, hipStream_t s);
 
@@ -156,6 +159,7 @@ size_t pipe_lds_bytes(Mode mode, int rows_per_wave, int waves, bool resident);
 bool pipe_has_variant(Mode mode, int rows_per_wave);
 // registers / occupancy of one instantiation (for the host-side launch plan)
 hipError_t pipe_kernel_attributes(Mode mode, int rows_per_wave, bool resident, int *num_regs);
+hipError_t grow_kernel_attributes(int rows_per_wave, int *num_regs);     // ... of the instantiation that walks a growing item list
 // mangled symbol of the instantiation (nullptr when there is none)
 const char *pipe_kernel_symbol(Mode mode, int rows_per_wave, bool dynamic, bool resident);
 hipError_t launch_pipe(Mode mode, int rows_per_wave, int waves, int n_wg, const PipeParams &p, hipStream_t s);
@@ -170,6 +174,9 @@ hipError_t launch_tile_sequences(const uint8_t *codes, const uint32_t *seq_off /
                                  const uint32_t *gcols, uint32_t dev_groups, uint32_t max_cols /* longest group */, uint8_t *tiled, hipStream_t s);
 
 // appends the slots whose score is >= thr (tier left its exact range) to list (up to cap) and zeroes them
+// items of a streaming search's list that are on the device (PipeParams::avail); kAvailAbort = the upload failed: give up
+constexpr uint32_t kAvailAbort = 0xFFFFFFFFu;
+hipError_t launch_publish_items(uint32_t *avail, uint32_t value, hipStream_t s);
 hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, int thr, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s);
 // per-block top-64 candidates of every query's score row (rows n_slots apart): out_keys[(query * n_blocks + block) * 64 + i] =
 // ((score<<32 | global index) + 1), 0 = empty; group_base[g] = global sorted index of the group's first sequence,

@@ -182,6 +182,14 @@ __device__ __forceinline__ v2h pair_score_plus(uint32_t xa, uint32_t xb, v2h hd)
     asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(xa), "v"(xb), "v"(hd));
     return t;
 }
+// a packed add whose second operand is wave-uniform and lives in a scalar register (the gap penalties in the lane-systolic
+// kernel, whose register budget is tight: a constant per VGPR less)
+__device__ __forceinline__ v2h pk_add_f16_s(v2h a, uint32_t s_bits)
+{
+    v2h d;
+    asm("v_pk_add_f16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(s_bits));
+    return d;
+}
 __device__ __forceinline__ void cell2_ofs(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2h &E1, v2h &Fp, v2h &best, uint32_t xa0, uint32_t xb0,
                                           uint32_t xa1, uint32_t xb1, v2h ngo, v2h nge, v2h fl)
 {
@@ -265,6 +273,33 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t x)
 }
 __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *q) { return (const uint8_t *)(uintptr_t)uniform_u64((uint64_t)(uintptr_t)q); }
 
+// A search that streams its database in for one query: the launch walks the whole item list in upload order while the parts
+// are still travelling.  Wave 0 calls this before it hands out item g: it polls the count the upload stream publishes behind
+// every part's tiling kernel (agent-scope loads, a sleep between polls) and takes an agent-scope acquire -- this CU's L1 is
+// invalidated -- when the count has grown; the other waves load the item's bytes after the step barrier that follows the
+// hand-out (MI355X_MICROARCH.md, inter-workgroup visibility: "consumer: poll, ONE agent acquire, barrier, plain loads"; the
+// producer side is a kernel boundary).  The wait is bounded (about a second without the count moving past the item): an
+// upload that fails publishes kAvailAbort (bit 8 of *err: the host discards the results); a wait that runs out sets bit 16
+// and the workgroup takes no further items -- the host then aligns the database once it is resident (search_device).  That
+// second case is not expected to happen: it would mean the tiling kernels cannot run beside this launch (the host picks a
+// launch shape that leaves them registers on every CU, issue_one_list), and must not become a hang.
+// `seen` caches the last count read (wave-uniform).
+__device__ __forceinline__ bool wait_landed(const uint32_t *avail, uint32_t g, uint32_t &seen, uint32_t *err)
+{
+    if (seen == kAvailAbort) return false;           // (gave up before: no second wait)
+    if (g < seen) return true;
+    for (uint32_t spins = 0;; ++spins) {
+        const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v == kAvailAbort) { atomicOr(err, 8u); seen = kAvailAbort; return false; }
+        seen = v;
+        if (g < v) break;
+        if (spins > (1u << 20)) { atomicOr(err, 16u); seen = kAvailAbort; return false; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
 // (text shared by the two places where the pipeline kernel requests its next chunk; uses the kernel's local state)
 #define SWIMM_REQUEST_NEXT_CHUNK() \
 { \
@@ -314,10 +349,14 @@ __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *q) { return
 //      profile rows of its own strip when the pass changes, so the pipeline never drains.  A group shorter than the
 //      pipeline (fewer chunks than waves) idles to the pipeline's depth between two of its passes: wave 0 must not
 //      start pass p+1 of a column before the last wave has finished pass p of it.
-template <int T, int M, bool DYN, bool RES>
+// GROW: the item list is still landing (PipeParams::avail, wait_landed above): wave 0 waits for an item's turn before it hands
+//      the item out.  An instantiation of its own (binary16 tier, dynamic queue, one pass), so that the kernels a resident
+//      database runs are exactly the ones their register budgets were tuned for.
+template <int T, int M, bool DYN, bool RES, bool GROW = false>
 __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const PipeParams p)
 {
     static_assert(T % 4 == 0 && T >= 8, "strips are multiples of 4 rows");
+    static_assert(!GROW || (DYN && !RES && M == 2), "a growing item list: dynamic queue, one launch per pass, binary16 tier");
     constexpr bool OFS = M == 2;          // binary16 tier: column-offset form, one profile dword per row (cell2_ofs)
     constexpr int TP = OFS ? T : strip_lds_rows(T);
     constexpr int RB = OFS ? 4 : 2;       // bytes per row of the LDS profile
@@ -369,16 +408,25 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
     // third one -- 35 % on a 1e8-residue database.)
     uint32_t pending = 0, pub = 2;
     bool pending_valid = false;
+    uint32_t landed = 0;          // streaming list (p.avail): items known to be on the device (wave 0)
     if (DYN) {
         // the first two rounds are dealt like LPT deals them when all workgroups start together: item b to
         // workgroup b, then the next gridDim.x items in reverse (the longest first item gets the shortest second
         // one); everything after that comes from the cursor.  (Letting every workgroup pull its first two items
         // from the cursor paired the two longest items on workgroup 0: -10 % on a small database.)
-        if (threadIdx.x == 0) {
-            const uint32_t g0 = blockIdx.x, g1 = 2 * gridDim.x - 1 - blockIdx.x;
-            seq[0] = g0 < p.n_items ? g0 : kNoItem;
-            seq[1] = g1 < p.n_items ? g1 : kNoItem;
-            *total_lds = g0 < p.n_items ? 0x3fffffff : 0;
+        if (threadIdx.x < 64) {       // (wave 0, uniform: lane 0 writes)
+            uint32_t g0 = blockIdx.x, g1 = 2 * gridDim.x - 1 - blockIdx.x;
+            if (g0 >= p.n_items) g0 = kNoItem;
+            if (g1 >= p.n_items) g1 = kNoItem;
+            if (GROW) {                                // the dealt items may still be on their way
+                if (g0 != kNoItem && !wait_landed(p.avail, g0, landed, p.err)) g0 = g1 = kNoItem;
+                if (g1 != kNoItem && !wait_landed(p.avail, g1, landed, p.err)) g1 = kNoItem;
+            }
+            if (threadIdx.x == 0) {
+                seq[0] = g0;
+                seq[1] = g1;
+                *total_lds = g0 != kNoItem ? 0x3fffffff : 0;
+            }
         }
         __syncthreads();
         it = seq[0];
@@ -467,8 +515,10 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             break;
         }
         if (DYN && k == 0 && pending_valid) {
-            const uint32_t g = __builtin_amdgcn_readfirstlane(pending) + 2 * gridDim.x;   // the cursor starts behind the two dealt rounds
-            if (lane == 0) seq[pub & (kSeqRing - 1)] = g < p.n_items ? g : kNoItem;
+            uint32_t g = __builtin_amdgcn_readfirstlane(pending) + 2 * gridDim.x;   // the cursor starts behind the two dealt rounds
+            if (g >= p.n_items) g = kNoItem;
+            if (GROW && g != kNoItem && !wait_landed(p.avail, g, landed, p.err)) g = kNoItem;
+            if (lane == 0) seq[pub & (kSeqRing - 1)] = g;
             ++pub;
             pending_valid = false;
         }
@@ -551,7 +601,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
             }
             // top boundary of the strip for these columns: H of the row above, F entering row 0
             uint2 bin[C];
-            const bool first_pass = RES ? pass == 0 : (bool)p.first_pass, last_pass = RES ? pass + 1 == passes : (bool)p.last_pass;
+            const bool first_pass = GROW ? true : RES ? pass == 0 : (bool)p.first_pass, last_pass = GROW ? true : RES ? pass + 1 == passes : (bool)p.last_pass;     // (GROW: one pass)
             const bool zero_top = (k == 0 || seam) && (first_pass || seam);      // no row above: H = F = 0 (OFS: o_j and o_j + ge, set column by column)
             if (k == 0 || seam) {
                 if (first_pass || seam) {
@@ -816,11 +866,34 @@ static hipError_t launch_any(Mode mode, int T, int W, int n_wg, const PipeParams
     return hipErrorInvalidValue;
 }
 
+template <int T>
+static hipError_t launch_grow_one(int W, int n_wg, const PipeParams &p, hipStream_t s)
+{
+    const size_t lds = pipe_lds_bytes(Mode::F16, T, W, false);
+    hipError_t e = hipFuncSetAttribute((const void *)sw_pipe_kernel<T, 2, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sw_pipe_kernel<T, 2, true, false, true>), dim3(n_wg), dim3(W * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+// the launch of a streaming search's one item list (PipeParams::avail): binary16 tier, dynamic queue, one pass
+static hipError_t launch_grow(int T, int W, int n_wg, const PipeParams &p, hipStream_t s)
+{
+    if (T == 32) return launch_grow_one<32>(W, n_wg, p, s);
+    if (T == 24) return launch_grow_one<24>(W, n_wg, p, s);
+    if (T == 16) return launch_grow_one<16>(W, n_wg, p, s);
+#define X(t) if (T == t) return launch_grow_one<t>(W, n_wg, p, s);
+    SWIMM_EXTRA_T(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_pipe(Mode mode, int T, int W, int n_wg, const PipeParams &p, hipStream_t s)
 {
     if (W < 1 || W > kMaxWaves || n_wg < 1 || !pipe_has_variant(mode, T)) return hipErrorInvalidValue;
     if (T > 28 && W > 12) return hipErrorInvalidValue;    // __launch_bounds__ of those instantiations
     const bool dyn = p.queue != nullptr;
+    if (p.avail != nullptr) return dyn && p.qdesc == nullptr && mode == Mode::F16 ? launch_grow(T, W, n_wg, p, s) : hipErrorInvalidValue;
     if (p.qdesc != nullptr) return dyn && p.n_queries > 0 ? launch_any<true, true>(mode, T, W, n_wg, p, s) : hipErrorInvalidValue;
     return dyn ? launch_any<true, false>(mode, T, W, n_wg, p, s) : launch_any<false, false>(mode, T, W, n_wg, p, s);
 }
@@ -851,6 +924,23 @@ hipError_t pipe_kernel_attributes(Mode mode, int T, bool resident, int *num_regs
     hipFuncAttributes a;
     const void *f = resident ? kernel_ptr_t<true, true>(mode, T) : kernel_ptr_t<true, false>(mode, T);
     if (!f) return hipErrorInvalidValue;
+    hipError_t e = hipFuncGetAttributes(&a, f);
+    if (e == hipSuccess) *num_regs = a.numRegs;
+    return e;
+}
+
+// registers of the instantiation that walks a growing item list (launch_grow)
+hipError_t grow_kernel_attributes(int T, int *num_regs)
+{
+    const void *f = nullptr;
+    if (T == 32) f = (const void *)sw_pipe_kernel<32, 2, true, false, true>;
+    if (T == 24) f = (const void *)sw_pipe_kernel<24, 2, true, false, true>;
+    if (T == 16) f = (const void *)sw_pipe_kernel<16, 2, true, false, true>;
+#define X(t) if (T == t) f = (const void *)sw_pipe_kernel<t, 2, true, false, true>;
+    SWIMM_EXTRA_T(X)
+#undef X
+    if (!f) return hipErrorInvalidValue;
+    hipFuncAttributes a;
     hipError_t e = hipFuncGetAttributes(&a, f);
     if (e == hipSuccess) *num_regs = a.numRegs;
     return e;
@@ -967,7 +1057,12 @@ __device__ __forceinline__ uint32_t dpp_shr1(uint32_t prev, uint32_t lane0_value
 
 constexpr uint32_t kFlagStart = 1u << 16, kFlagEnd = 1u << 17, kFlagReal = 1u << 18;   // kFlagReal: a column of an item (not pipeline fill/drain)
 
-size_t lane_lds_bytes(int rows_per_lane) { return round16((size_t)kCodes * prof_row_bytes(64 * rows_per_lane)); }
+// LDS of a lane-systolic workgroup: the pass's 64 x rows-per-lane profile rows of all 25 codes; the binary16 tier holds a dword
+// (score + ge, 1.0) per row like the pipeline kernel's (pair_score_plus), the integer tiers two rows per dword
+size_t lane_lds_bytes(Mode mode, int rows_per_lane)
+{
+    return round16((size_t)kCodes * (mode == Mode::F16 ? prof_row_bytes_f16(64 * rows_per_lane) : prof_row_bytes(64 * rows_per_lane)));
+}
 
 // what lane 0 feeds into the pipeline for one chunk of 4 columns (wave-uniform)
 struct LaneFeed {
@@ -994,8 +1089,8 @@ struct LaneFeed {
 template <int NW>
 __device__ __forceinline__ void lane_prof_load(const unsigned char *q, uint32_t (&w)[NW])
 {
-    if (NW == 4) { const uint4 v = *(const uint4 *)q; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-    else if (NW == 2) { const uint2 v = *(const uint2 *)q; w[0] = v.x; w[1] = v.y; }
+    if constexpr (NW == 4) { const uint4 v = *(const uint4 *)q; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    else if constexpr (NW == 2) { const uint2 v = *(const uint2 *)q; w[0] = v.x; w[1] = v.y; }
     else { w[0] = *(const uint32_t *)q; }
 }
 
@@ -1003,18 +1098,27 @@ __device__ __forceinline__ void lane_prof_load(const unsigned char *q, uint32_t 
 // 128 rows, whose step -- a serial walk down the lane's rows -- is then that much shorter, and with it the time a
 // 35 000-residue sequence holds up a short query.
 // M: 0 = packed int16 pairs, 1 = int32 (one sequence), 2 = packed binary16 pairs (the first tier of the long-sequence
-// tail: max3 makes a row 8.5 instead of 10 packed operations and its serial F chain three instead of four long;
-// alignments that reach 2048 are re-run in int16 by the promotion ladder, like the pipeline kernel's).
+// tail; alignments that leave its exact range are re-run in int16 by the promotion ladder, like the pipeline kernel's).
+// The binary16 tier runs the pipeline kernel's cell update -- OFFSET form, 6.5 packed operations per row pair, the pair's score
+// formed inside the v_pk_fma_f16 that adds the diagonal (cell2_ofs above) -- with the offsets counted by STEP instead of by
+// column: at step s every lane stores its values with o_s = (s mod P) * ge added.  A lane's consecutive steps are consecutive
+// columns, so inside a lane everything is as in the pipeline kernel (E's decay is the offset's growth).  Between lanes a value
+// crosses one step: lane l - 1 computed the column at step s - 1, lane l takes it at step s.  The F it hands down, F + o_{s-1}
+// + ge, IS row 0's `a` = F + o_s -- the first subtraction of the row falls away -- and the H it hands down becomes the next
+// step's diagonal after one + ge.  Every P steps all carried state (H*, E*, the diagonal, the running best, the two values in
+// flight between lanes) is taken back by P * ge.  The running best of an ALIGNMENT (the T stream) and the boundary rows in
+// HBM stay in real space: converted where they leave / enter a lane's registers, once per item / per boundary column.
 template <int M, int TR>
 __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
 {
     constexpr bool PK = M != 1;
     typedef typename std::conditional<M == 0, OpsPK, typename std::conditional<M == 1, OpsI32, OpsF16>::type>::type Ops;
     typedef typename Ops::V V;
-    constexpr int C = kChunkCols, RP = 64 * TR, NW = TR / 2;   // NW dwords of profile per lane and residue
+    constexpr bool OFS = M == 2;                                   // binary16 tier: offset form, a profile dword (score + ge, 1.0) per row
+    constexpr int C = kChunkCols, RP = 64 * TR, NW = OFS ? TR : TR / 2;   // NW dwords of profile per lane and residue
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    const int PS = prof_row_bytes(RP);
+    const int PS = OFS ? prof_row_bytes_f16(RP) : prof_row_bytes(RP);
     const uint32_t bm = p.block_map[blockIdx.x];
     const uint32_t pass = bm & 0xffu;
     const LaneQ lq = p.lq[bm >> 8];
@@ -1035,9 +1139,11 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             const int d = idx / dw_per_code, x = idx - d * dw_per_code;
             const uint32_t *src = (const uint32_t *)(p.prof + lq.prof_off + (size_t)d * lq.prof_stride + r0);
             uint32_t v = src[x];
-            if (M == 2) {                           // int16 scores -> binary16
+            if (OFS) {                              // int16 scores -> (binary16 of score + ge, 1.0) per row (pair_score_plus)
                 const v2s sv = as_v2s(v);
-                v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)sv.x, (_Float16)(float)sv.y});
+                *(uint2 *)(smem + d * PS + x * 8) = make_uint2(__builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.x + p.ge), (_Float16)1.0f}),
+                                                               __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.y + p.ge), (_Float16)1.0f}));
+                continue;
             }
             *(uint32_t *)(smem + d * PS + x * 4) = v;
         }
@@ -1046,9 +1152,19 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     // these waves are long serial chains (the longest alignments, or re-runs a query is waiting for) beside bulk waves
     // that step through priorities 3..0: stay near the top (priority 0 or 3 measured the same on c3)
     __builtin_amdgcn_s_setprio(2);
-    const unsigned char *my_prof = smem + lane * TR * 2;
+    const unsigned char *my_prof = smem + lane * TR * (OFS ? 4 : 2);
     const int last_lane = (int)((rows + TR - 1) / TR) - 1;      // lane holding the query's last rows in this pass
     const V goe = Ops::splat(M == 2 ? -p.goe : p.goe), ge = Ops::splat(M == 2 ? -p.ge : p.ge);
+    // offset form (binary16 tier): o_s and o_s + ge of the current step, steps since the last renormalisation, and the constants
+    // (wave-uniform: scalar operands of the packed adds -- the register budget of this kernel is 80)
+    const V ngo = Ops::splat(-(p.goe - p.ge)), pge = Ops::splat(p.ge);
+    const uint32_t renorm_steps = OFS ? (uint32_t)(kChunkCols * f16_renorm_chunks(p.ge)) : 0u;
+    const V nren = Ops::splat(-(int)renorm_steps * p.ge);
+    V off = Ops::zero(), fl = pge;                 // (fl: o_s + ge)
+    uint32_t since = 0;
+    const uint32_t s_ngo = __builtin_amdgcn_readfirstlane(Ops::bits(ngo)), s_nge = __builtin_amdgcn_readfirstlane(Ops::bits(ge));
+    const uint32_t s_pge = __builtin_amdgcn_readfirstlane(Ops::bits(pge)), s_nren = __builtin_amdgcn_readfirstlane(Ops::bits(nren));
+    auto adds = [](V x, uint32_t s_bits) -> V { if constexpr (OFS) return pk_add_f16_s(x, s_bits); else return x; };
 
     V H[TR], E[TR];
 #pragma unroll
@@ -1058,7 +1174,12 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     // can issue the profile reads of its next column before it computes the current one.
     uint32_t oDn = 0x1818u;                  // residues this lane will hand to lane+1 (already one step ahead)
     uint32_t Dcur = 0x1818u;                 // residues + flags of the column this lane computes in this step
-    uint32_t acur[NW] = {}, bcur[NW] = {};
+    // The scores of a lane's rows for its next column are looked up one step ahead -- the first NLO dwords (one ds_read_b128 per
+    // residue); a strip of more rows than that (the binary16 tier's 8 rows = 8 dwords) fetches the rest at the top of the
+    // step that uses them: the first rows' arithmetic covers the LDS round trip, and 8 fewer registers are live.  Two buffers
+    // in alternation (the chunk loop is unrolled by an even count): no copies from "next" to "current".
+    constexpr int NLO = NW < 4 ? NW : 4, NHI = NW - NLO;
+    uint32_t abuf[2][NLO] = {}, bbuf[2][NLO] = {};
     uint32_t oH = 0, oF = 0, oT = 0, oS = 0, oC = 0;
     uint2 pb = make_uint2(0u, 0u);           // boundary-side values of the column lane 0 fed one step ago
     uint32_t pitem = 0, pcol = 0;
@@ -1164,22 +1285,65 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             if (PK) d0 |= ((cur.wb >> (8 * jj)) & 0xffu) << 8;
             // residue stream, one step ahead: fetch the scores of the NEXT column now
             const uint32_t Dn = dpp_shr1(oDn, d0);
-            uint32_t an[NW], bn[NW] = {};
-            lane_prof_load<NW>(my_prof + (Dn & 0xffu) * PS, an);
-            if (PK) lane_prof_load<NW>(my_prof + ((Dn >> 8) & 0xffu) * PS, bn);
+            static_assert(C % 2 == 0, "the lookup buffers alternate column by column");
+            uint32_t (&acur)[NLO] = abuf[jj & 1], (&bcur)[NLO] = bbuf[jj & 1];
+            uint32_t (&an)[NLO] = abuf[(jj + 1) & 1], (&bn)[NLO] = bbuf[(jj + 1) & 1];
+            lane_prof_load<NLO>(my_prof + (Dn & 0xffu) * PS, an);
+            if (PK) lane_prof_load<NLO>(my_prof + ((Dn >> 8) & 0xffu) * PS, bn);
+            uint32_t ahi[NHI ? NHI : 1] = {}, bhi[NHI ? NHI : 1] = {};      // ... and the rest of THIS column's
+            if constexpr (NHI > 0) {
+                lane_prof_load<NHI>(my_prof + (Dcur & 0xffu) * PS + NLO * 4, ahi);
+                lane_prof_load<NHI>(my_prof + ((Dcur >> 8) & 0xffu) * PS + NLO * 4, bhi);
+            }
             // boundary stream: every lane takes its left neighbour's bottom row, lane 0 the stored top boundary
             const uint32_t Hin = dpp_shr1(oH, pb.x), Fin = dpp_shr1(oF, pb.y);
             const uint32_t Tin = dpp_shr1(oT, 0u), Sin = dpp_shr1(oS, pitem), Cin = dpp_shr1(oC, pcol);
             const uint32_t D = Dcur;
             if (D & kFlagStart) {                 // first column of an alignment reaches this lane
+                if constexpr (OFS) {              // "column -1" holds H = 0 in the previous step's space; E may start below the floor (cell2_ofs)
 #pragma unroll
-                for (int r = 0; r < TR; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
-                best = Ops::zero(); diag = Ops::zero();
+                    for (int r = 0; r < TR; ++r) { H[r] = adds(off, s_nge); E[r] = Ops::zero(); }
+                    best = off; diag = H[0];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+                    best = Ops::zero(); diag = Ops::zero();
+                }
             }
             V hd = diag;
-            diag = Ops::from_bits(Hin);
-            V F = Ops::from_bits(Fin);
             const uint32_t *aw = acur;
+            V F;
+            auto xa = [&](int r) { return r < NLO ? acur[r < NLO ? r : 0] : ahi[r >= NLO ? r - NLO : 0]; };      // row r's profile dword, residue A / B
+            auto xb = [&](int r) { return r < NLO ? bcur[r < NLO ? r : 0] : bhi[r >= NLO ? r - NLO : 0]; };
+            if constexpr (OFS) {
+                // the row above was computed one step ago: its H + o_{s-1} becomes the next step's diagonal after + ge, and its
+                // F' = F + o_{s-1} + ge is F + o_s already -- row 0's `a`
+                diag = adds(Ops::from_bits(Hin), s_pge);
+                V a = Ops::from_bits(Fin);
+#pragma unroll
+                for (int r = 0; r < TR; r += 2) {
+                    const V t0 = pair_score_plus(xa(r), xb(r), hd);
+                    hd = H[r];
+                    const V h0 = OpsF16::max3(t0, E[r], a);
+                    H[r] = h0;
+                    const V u0 = pk_add_f16_s(h0, s_ngo);
+                    E[r] = pk_max_f16(E[r], u0);
+                    F = OpsF16::max3(a, u0, fl);
+                    a = pk_add_f16_s(F, s_nge);
+                    const V t1 = pair_score_plus(xa(r + 1), xb(r + 1), hd);
+                    hd = H[r + 1];
+                    const V h1 = OpsF16::max3(t1, E[r + 1], a);
+                    H[r + 1] = h1;
+                    const V u1 = pk_add_f16_s(h1, s_ngo);
+                    E[r + 1] = pk_max_f16(E[r + 1], u1);
+                    F = OpsF16::max3(a, u1, fl);
+                    if (r + 2 < TR) a = pk_add_f16_s(F, s_nge);
+                    best = OpsF16::max3(best, h0, h1);
+                    asm("" : "+v"(best));
+                }
+            } else {
+            diag = Ops::from_bits(Hin);
+            F = Ops::from_bits(Fin);
             if constexpr (PK) {
                 const uint32_t *bw = bcur;
 #pragma unroll
@@ -1193,11 +1357,18 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
                     cell<Ops>(hd, H[2 * q + 1], E[2 * q + 1], F, best, Ops::from_bits((uint32_t)((int)aw[q] >> 16)), goe, ge);
                 }
             }
+            }
             oH = Ops::bits(H[TR - 1]); oF = Ops::bits(F); oS = Sin; oC = Cin; oT = Tin;
-            if (D & kFlagEnd) oT = Ops::bits(Ops::vmax(Ops::from_bits(Tin), best));   // running best of the alignment
+            if (D & kFlagEnd) {                   // running best of the alignment (the T stream is in real space)
+                if constexpr (OFS) oT = Ops::bits(Ops::vmax(Ops::from_bits(Tin), best - off));
+                else oT = Ops::bits(Ops::vmax(Ops::from_bits(Tin), best));
+            }
             const bool mine = lane == last_lane && (D & kFlagReal);   // fill / drain columns must never reach real memory
-            if (!last_pass && mine)   // one lane, four stores per real chunk (lane 63's chunks are chunk aligned)
-                __hip_atomic_store(bnd_out + Cin, ((unsigned long long)oF << 32) | oH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!last_pass && mine) {   // one lane, four stores per real chunk (lane 63's chunks are chunk aligned); real space in HBM
+                uint32_t sH = oH, sF = oF;
+                if constexpr (OFS) { sH = Ops::bits(H[TR - 1] - off); sF = Ops::bits(F - fl); }
+                __hip_atomic_store(bnd_out + Cin, ((unsigned long long)sF << 32) | sH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (mine && (D & kFlagEnd)) {   // every pass contributes the best of its own rows
                 const LaneItem *iv = items + Sin;
                 if (M == 2) {
@@ -1214,9 +1385,23 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             }
             // advance both streams
             oDn = Dn; Dcur = Dn;
-#pragma unroll
-            for (int q = 0; q < NW; ++q) { acur[q] = an[q]; bcur[q] = bn[q]; }
             pb = cur.b[jj]; pitem = cur.item; pcol = cur.col0 + jj;
+            if constexpr (OFS) {
+                // what lane 0 takes next step must look like a lane's hand-over of THIS step: H + o_s, F + o_s + ge (the stored
+                // boundary rows are in real space; the first pass has none: H = F = 0)
+                pb = first_pass ? make_uint2(Ops::bits(off), Ops::bits(fl))
+                                : make_uint2(Ops::bits(Ops::from_bits(pb.x) + off), Ops::bits(Ops::from_bits(pb.y) + fl));
+                best = adds(best, s_pge);                    // the running best, in the next step's space
+                off = fl; fl = adds(fl, s_pge);              // o_{s+1}
+                if (++since == renorm_steps) {               // the offsets have grown for P steps: take every carried value back by P * ge
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) { H[r] = adds(H[r], s_nren); E[r] = adds(E[r], s_nren); }
+                    diag = adds(diag, s_nren); best = adds(best, s_nren);
+                    oH = Ops::bits(adds(Ops::from_bits(oH), s_nren)); oF = Ops::bits(adds(Ops::from_bits(oF), s_nren));
+                    pb = make_uint2(Ops::bits(adds(Ops::from_bits(pb.x), s_nren)), Ops::bits(adds(Ops::from_bits(pb.y), s_nren)));
+                    off = Ops::zero(); fl = Ops::from_bits(s_pge); since = 0;
+                }
+            }
         }
         if (!last_pass && ((hist_real >> 16) & 1u)) {
             // Lane 63 has just stored the boundary of the chunk fed 16 iterations ago, which ends at column oC of item
@@ -1230,7 +1415,7 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
 template <int TR>
 static hipError_t launch_lane_tr(Mode mode, int n_wg, const LaneParams &p, hipStream_t s)
 {
-    const size_t lds = lane_lds_bytes(TR);
+    const size_t lds = lane_lds_bytes(mode, TR);
     if (mode == Mode::PK16) hipLaunchKernelGGL((sw_lane_kernel<0, TR>), dim3(n_wg), dim3(256), lds, s, p);
     else if (mode == Mode::F16) hipLaunchKernelGGL((sw_lane_kernel<2, TR>), dim3(n_wg), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((sw_lane_kernel<1, TR>), dim3(n_wg), dim3(256), lds, s, p);
@@ -1274,39 +1459,36 @@ __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__r
     const uint32_t nch = gcols[g] / kChunkCols;
     const uint32_t per = kGroupSeqs / vl;            // VL-groups per device group
     // (blockIdx.y: a long group is shared by several blocks -- a chunk of 5 000-residue sequences has fewer groups than the chip has CUs)
-    for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nch * 64; idx += gridDim.y * blockDim.x) {
-        const uint32_t c = idx >> 6, l = idx & 63;
-        uint32_t w[2];
+    // One (chunk, sequence) dword per thread and iteration: the kernel must fit the 32 registers a CU full of pipeline waves
+    // leaves free (4 waves x 120 of a SIMD's 512), or a search that streams its database in would wait for a workgroup to end
+    // before the next chunk could be tiled (tests/test_codegen.py holds the count).
+    for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nch * 128; idx += gridDim.y * blockDim.x) {
+        const uint32_t c = idx >> 7, sl = idx & 127;      // sequence within the device group: lane sl / 2, half sl % 2
+        const uint32_t v = g * per + sl / vl, kk = sl % vl;
+        uint32_t word = 0, real_end = 0;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const uint32_t sl = 2 * l + hh;           // sequence within the device group
-            const uint32_t v = g * per + sl / vl, kk = sl % vl;
-            uint32_t word = 0, real_end = 0;
-#pragma unroll
-            for (int jj = 0; jj < kChunkCols; ++jj) {
-                const uint32_t col = c * kChunkCols + jj;
-                uint32_t code = 24;                   // PREPROCESSED_DUMMY_ELEMENT, sequences.h:18
-                if (v < vl_groups && col < n[v]) {
-                    code = b[(size_t)disp[v] + (size_t)col * vl + kk];
-                    if (code > 24) code = 24;         // out-of-alphabet bytes score like padding
-                }
-                if (code != 24) real_end = col + 1;
-                word |= dev_code(code) << (8 * jj);
+        for (int jj = 0; jj < kChunkCols; ++jj) {
+            const uint32_t col = c * kChunkCols + jj;
+            uint32_t code = 24;                   // PREPROCESSED_DUMMY_ELEMENT, sequences.h:18
+            if (v < vl_groups && col < n[v]) {
+                code = b[(size_t)disp[v] + (size_t)col * vl + kk];
+                if (code > 24) code = 24;         // out-of-alphabet bytes score like padding
             }
-            w[hh] = word;
-            // true length of every sequence = 1 + its last non-padding column (the reference layout only
-            // carries group lengths); the lane-systolic kernel stops each alignment there
-            if (real_end) atomicMax(seq_len + (size_t)g * kGroupSeqs + sl, real_end);
+            if (code != 24) real_end = col + 1;
+            word |= dev_code(code) << (8 * jj);
         }
-        *(uint2 *)(tiled + goff[g] + (size_t)idx * 8) = make_uint2(w[0], w[1]);
+        // true length of every sequence = 1 + its last non-padding column (the reference layout only
+        // carries group lengths); the lane-systolic kernel stops each alignment there
+        if (real_end) atomicMax(seq_len + (size_t)g * kGroupSeqs + sl, real_end);
+        *(uint32_t *)(tiled + goff[g] + (size_t)idx * 4) = word;      // [chunk][lane][A0..A3 | B0..B3]: dword idx = (c * 64 + lane) * 2 + half
     }
 }
 
-// blocks per group of the two tiling kernels: four (chunk, lane) pairs per thread for the longest group, at most 32
+// blocks per group of the two tiling kernels: eight (chunk, sequence) dwords per thread for the longest group, at most 32
 static unsigned tile_slices(uint32_t max_cols)
 {
-    const uint32_t pairs = max_cols / kChunkCols * 64;
-    return std::max(1u, std::min(32u, (pairs + 1023) / 1024));
+    const uint32_t dwords = max_cols / kChunkCols * 128;
+    return std::max(1u, std::min(32u, (dwords + 2047) / 2048));
 }
 
 hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t vl_groups, uint32_t vl,
@@ -1330,37 +1512,32 @@ __global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const u
     __builtin_amdgcn_s_setprio(3);                    // (see retile_kernel)
     const uint32_t g = blockIdx.x;
     const uint32_t nch = gcols[g] / kChunkCols;
-    for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nch * 64; idx += gridDim.y * blockDim.x) {
-        const uint32_t c = idx >> 6, l = idx & 63;
-        uint32_t w[2];
+    for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nch * 128; idx += gridDim.y * blockDim.x) {
+        const uint32_t c = idx >> 7;
+        const uint32_t s = g * kGroupSeqs + (idx & 127);          // (one (chunk, sequence) dword per thread and iteration: see retile_kernel)
+        uint32_t word = 0x18181818u;              // four padding codes (24)
+        if (s < n_seq) {
+            const uint32_t b0 = seq_off[s], len = seq_off[s + 1] - b0;
+            const uint32_t col = c * kChunkCols;
+            if (col + kChunkCols <= len) {
+                // four residues inside the sequence: one (unaligned) dword, codes above 24 clamped to the padding code
+                uint32_t x;
+                __builtin_memcpy(&x, codes + (size_t)b0 + col, 4);
+                const uint32_t over = ((x & 0x80808080u) | (((x & 0x7f7f7f7fu) + 0x67676767u) & 0x80808080u)) >> 7;   // 1 per byte > 24
+                const uint32_t m = over * 0xffu;
+                x = (x & ~m) | (0x18181818u & m);
+                word = dev_code(x & 0xffu) | dev_code((x >> 8) & 0xffu) << 8 | dev_code((x >> 16) & 0xffu) << 16 | dev_code(x >> 24) << 24;
+            } else {
+                word = 0;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const uint32_t s = g * kGroupSeqs + 2 * l + hh;
-            uint32_t word = 0x18181818u;              // four padding codes (24)
-            if (s < n_seq) {
-                const uint32_t b0 = seq_off[s], len = seq_off[s + 1] - b0;
-                const uint32_t col = c * kChunkCols;
-                if (col + kChunkCols <= len) {
-                    // four residues inside the sequence: one (unaligned) dword, codes above 24 clamped to the padding code
-                    uint32_t x;
-                    __builtin_memcpy(&x, codes + (size_t)b0 + col, 4);
-                    const uint32_t over = ((x & 0x80808080u) | (((x & 0x7f7f7f7fu) + 0x67676767u) & 0x80808080u)) >> 7;   // 1 per byte > 24
-                    const uint32_t m = over * 0xffu;
-                    x = (x & ~m) | (0x18181818u & m);
-                    word = dev_code(x & 0xffu) | dev_code((x >> 8) & 0xffu) << 8 | dev_code((x >> 16) & 0xffu) << 16 | dev_code(x >> 24) << 24;
-                } else {
-                    word = 0;
-#pragma unroll
-                    for (int jj = 0; jj < kChunkCols; ++jj) {
-                        uint32_t code = 24;
-                        if (col + jj < len) { code = codes[(size_t)b0 + col + jj]; if (code > 24) code = 24; }
-                        word |= dev_code(code) << (8 * jj);
-                    }
+                for (int jj = 0; jj < kChunkCols; ++jj) {
+                    uint32_t code = 24;
+                    if (col + jj < len) { code = codes[(size_t)b0 + col + jj]; if (code > 24) code = 24; }
+                    word |= dev_code(code) << (8 * jj);
                 }
             }
-            w[hh] = word;
         }
-        *(uint2 *)(tiled + goff[g] + (size_t)idx * 8) = make_uint2(w[0], w[1]);
+        *(uint32_t *)(tiled + goff[g] + (size_t)idx * 4) = word;
     }
 }
 
@@ -1369,6 +1546,24 @@ hipError_t launch_tile_sequences(const uint8_t *codes, const uint32_t *seq_off, 
 {
     if (dev_groups == 0) return hipSuccess;
     hipLaunchKernelGGL(tile_sequences_kernel, dim3(dev_groups, tile_slices(max_cols)), dim3(256), 0, s, codes, seq_off, n_seq, goff, gcols, tiled);
+    return hipGetLastError();
+}
+
+// ---- "this much of the item list has landed" ------------------------------------------------------
+// A search that streams its database in for ONE query runs ONE pipeline launch over the whole item list, in the order the
+// parts travel (sw_pipe_kernel, PipeParams::avail); this one-thread kernel follows every part's tiling kernel on the upload
+// stream and publishes how many items of the list are on the device now.  The tiling kernel has ended by then -- its stores are
+// written back at the kernel boundary -- and the store below is agent-scope (sc1: write-through); the consumer polls with
+// agent-scope loads and takes an agent-scope acquire before the first load of the new items' bytes (form "producer release,
+// then flag; consumer poll, acquire, barrier, plain loads" of MI355X_MICROARCH.md, inter-workgroup visibility).
+__global__ void publish_items_kernel(uint32_t *avail, uint32_t value)
+{
+    __hip_atomic_store(avail, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t launch_publish_items(uint32_t *avail, uint32_t value, hipStream_t s)
+{
+    hipLaunchKernelGGL(publish_items_kernel, dim3(1), dim3(1), 0, s, avail, value);
     return hipGetLastError();
 }
 

@@ -149,7 +149,10 @@ struct ChunkRec {
 
 // what travels in one go: the device groups [g0, g1) of a chunk (the whole chunk, or -- for the chunk a streaming search
 // starts with -- a small head part, so that the first launch has its data a few hundred microseconds after the call)
-struct UploadPart { size_t chunk = 0; uint32_t g0 = 0, g1 = 0; hipEvent_t ready = nullptr; };
+struct UploadPart {
+    size_t chunk = 0; uint32_t g0 = 0, g1 = 0; hipEvent_t ready = nullptr;
+    uint32_t publish = 0;       // > 0: once the part has landed, this many items of the search's one item list are on the device (PipeParams::avail)
+};
 
 struct QueryPlan {
     int T, W, passes; uint32_t mpad; size_t prof_off; Mode mode = Mode::F16; bool dynamic = true, resident = false;
@@ -217,6 +220,9 @@ struct swimm_hip_ctx {
     // caches that depend on the resident database / the code objects
     BulkCols bulk;                      // the resident database's bulk groups (built on demand) and their makespan factors
     int regs_cache[2][3][40] = {};      // VGPRs of sw_pipe_kernel<T, tier, dynamic, group-resident or not>, looked up once
+    hipEvent_t ev_avail = nullptr;      // ... its count has been reset (on the upload stream)
+    DevBuf<uint32_t> d_avail;           // streaming search with one item list: how many of its items have landed (publish_items_kernel)
+    DevBuf<Item> d_stream_items;        // ... and that list (every group of the database, in the order the parts travel)
     DevBuf<uint32_t> d_queue;           // one cursor per pipeline launch of a search
     uint32_t queue_next = 0;
     // queries (host copies; profiles are built per search because T/W may change)
@@ -331,6 +337,9 @@ struct Uploader {
                 bool skip;
                 { std::lock_guard<std::mutex> g(mu); skip = stop; }
                 if (ok && !skip && upload_part(c, c->chunks[job[i].chunk], job[i].g0, job[i].g1, job[i].ready)) { ok = false; e = g_err; }
+                // (a search that walks ONE item list while the database streams in: tell its launch how far the list has landed --
+                // behind the part's tiling kernel on the same stream; also for a part that was on the device already)
+                if (ok && !skip && job[i].publish && launch_publish_items(c->d_avail.p, job[i].publish, c->stream_up) != hipSuccess) { ok = false; e = "publish_items launch failed"; }
                 std::lock_guard<std::mutex> g(mu);
                 issued = i + 1; failed = !ok; err = e;
                 cv.notify_all();

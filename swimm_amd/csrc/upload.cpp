@@ -95,6 +95,8 @@ int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEven
     uint32_t max_cols = 0;
     for (uint32_t g = g0; g < g1; ++g) max_cols = std::max(max_cols, r.gcols[g]);
     const double t_up0 = now_s();
+    const bool dbg_t = getenv("SWIMM_HIP_DEBUG_UPLOAD") != nullptr;
+    double t_a = 0, t_b = 0, t_c = 0;
     uint64_t bytes = 0;
     HIP_TRY(c->up_gcols.reserve(dev_groups));
     HIP_TRY(c->up_goff.reserve(dev_groups));
@@ -112,7 +114,9 @@ int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEven
         HIP_TRY(hipMemsetAsync(r.d_len + (size_t)g0 * kGroupSeqs, 0, (size_t)dev_groups * kGroupSeqs * sizeof(uint32_t), s));
         HIP_TRY(hipMemcpyAsync(c->up_n.p, r.h_n + v0, (v1 - v0) * sizeof(uint16_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->up_disp.p, r.h_disp + v0, (v1 - v0) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        t_a = now_s();
         HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_b + b0, bytes, hipMemcpyHostToDevice, s));
+        t_b = now_s();
         HIP_TRY(hipEventRecord(c->ev_copied, s));
         HIP_TRY(launch_retile(c->up_b.p - b0, c->up_n.p, c->up_disp.p, v1 - v0, r.vl, c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled,
                               r.d_len + (size_t)g0 * kGroupSeqs, s));
@@ -123,12 +127,18 @@ int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEven
         HIP_TRY(c->up_b.reserve(std::max<uint64_t>(bytes, 16)));
         HIP_TRY(c->up_off.reserve(s1 - s0 + 1));
         HIP_TRY(hipMemcpyAsync(c->up_off.p, r.off.data() + s0, (s1 - s0 + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        t_a = now_s();
         HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_codes + o0, bytes, hipMemcpyHostToDevice, s));
+        t_b = now_s();
         HIP_TRY(hipEventRecord(c->ev_copied, s));
         HIP_TRY(launch_tile_sequences(c->up_b.p - o0, c->up_off.p, (uint32_t)(s1 - s0), c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled, s));
     }
     HIP_TRY(hipEventRecord(ready ? ready : r.ready, s));
+    t_c = now_s();
     HIP_TRY(hipEventSynchronize(c->ev_copied));      // the caller's buffers have been read
+    if (dbg_t)
+        fprintf(stderr, "swimm_hip: upload part: small copies returned after %.3f ms, the %.1f MB copy after %.3f, tiling kernel launched after %.3f, copy event reached after %.3f\n",
+                (t_a - t_up0) * 1e3, bytes / 1e6, (t_b - t_up0) * 1e3, (t_c - t_up0) * 1e3, (now_s() - t_up0) * 1e3);
     if (getenv("SWIMM_HIP_DEBUG"))
         fprintf(stderr, "swimm_hip: %s of %.1f MB copied in %.2f ms (%.1f GB/s)\n", dev_groups == r.n_groups ? "chunk" : "part of a chunk", bytes / 1e6, (now_s() - t_up0) * 1e3,
                 bytes / 1e9 / (now_s() - t_up0));

@@ -50,13 +50,28 @@ def test_c2_full_size(c2):
                  {"bnd_mib": 64, "rows_per_wave": 16, "waves": 4}):
         other, _ = _search(shard, chunks, opts)
         assert np.array_equal(base, other), opts
-    sm = submat.table("blosum62")
+    # the first search after a cold upload -- ONE launch walks the whole item list while the chunks are still travelling
+    # (PipeParams::avail) -- must give the same 1 000 004 scores as the resident database, through chunks and through slabs,
+    # also with a handful of workgroups that wait for every part
+    for opts in ({"lazy_upload": 1}, {"lazy_upload": 1, "wg_limit": 40}, {"lazy_upload": 1, "upload_piece_kib": 8192}):
+        other, _ = _search(shard, chunks, opts)
+        assert np.array_equal(base, other), opts
     q = shard["query"]
+    offs = np.concatenate([[0], np.cumsum(shard["lengths"].astype(np.int64))])
+    with hip_backend.HipSearcher(0) as s:
+        s.set_option("lazy_upload", 1)
+        s.set_queries(q, np.array([len(q)], np.uint16), np.array([0, len(q)], np.uint32), submat.table("blosum62"), 10, 2)
+        for first in range(0, shard["n"], 1 << 17):
+            e = min(shard["n"], first + (1 << 17))
+            s.add_sequences(shard["lengths"][first:e], shard["codes"][offs[first]:offs[e]], first)
+        streamed, _ = s.search((shard["n"] + 127) // 128 * 128)
+        assert s.last_stats()["launches"] == 1
+    assert np.array_equal(base, streamed[0, :shard["n"]])
+    sm = submat.table("blosum62")
     self_score = port.pair_score(q, q, sm, 10, 2)
     order = np.argsort(-base.astype(np.int64), kind="stable")
     assert base[order[0]] == self_score                       # planted 0 % copy
     assert base[order[0]] > base[order[1]] > base[order[2]] > base[order[3]] > base[order[4]]   # 10/30/50 % copies, then background
-    offs = np.concatenate([[0], np.cumsum(shard["lengths"].astype(np.int64))])
     rng = np.random.default_rng(7)
     picks = list(rng.integers(0, shard["n"], 400)) + [0, shard["n"] - 1] + list(order[:20])
     for i in picks:

@@ -249,6 +249,42 @@ def test_streaming_upload_c2_shape():
     chunks.close()
 
 
+@pytest.mark.parametrize("opts", [{}, {"wg_limit": 3}, {"upload_piece_kib": 16}, {"upload_piece_kib": 16, "wg_limit": 2, "rows_per_wave": 24},
+                                  {"f16": 0}, {"max_waves": 4}, {"tail_mode": 1}])
+def test_one_query_walks_one_list_while_the_database_lands(tmp_path, golden, opts):
+    """A streaming search for ONE query that fits one pass is ONE pipeline launch over one item list in upload order; its
+    workgroups wait for the parts as they land (PipeParams::avail, publish_items_kernel).  Every golden query on its own, many
+    small parts, two or three workgroups that take everything (each waits for every part), the promotion ladder behind it:
+    the golden scores, and one launch where the path applies."""
+    q, pp, chunked = golden_inputs(tmp_path, golden, vl=128, max_chunk=9000)
+    N = golden["search"]["n_sequences"]
+    want = load_npy("scores_blosum62_g10_e2.npy")
+    lens, codes = pp["lengths"].astype(np.uint16), pp["codes"]
+    offs = np.concatenate([[0], np.cumsum(pp["lengths"])])
+    for k in range(len(q["m"])):
+        a = q["a"][q["disp"][k]:q["disp"][k] + q["m"][k]]
+        m, disp = np.array([q["m"][k]], np.uint16), np.array([0, q["m"][k]], np.uint32)
+        for path in ("chunks", "slabs"):
+            with hip_backend.HipSearcher(0) as s:
+                for key, v in opts.items():
+                    s.set_option(key, v)
+                s.set_option("lazy_upload", 1)
+                s.set_queries(a, m, disp, matrix("blosum62"), 10, 2)
+                if path == "chunks":
+                    stride = load_chunks(s, chunked, 128) * 128
+                else:
+                    for s0 in range(0, N, 256):
+                        s1 = min(N, s0 + 256)
+                        s.add_sequences(lens[s0:s1], codes[offs[s0]:offs[s1]], first_seq=s0)
+                    stride = (N + 127) // 128 * 128
+                first, _ = s.search(stride)
+                st, plan = s.last_stats(), s.last_plan(0)
+                again, _ = s.search(stride)
+            assert np.array_equal(first[0, :N], want[k]) and np.array_equal(again[0, :N], want[k]), (k, path, opts)
+            if plan["passes"] == 1 and opts.get("f16", 1) and int(q["m"][k]) <= 400:
+                assert st["launches"] <= 1 + 2 * 2, (k, path, opts, st)      # the one launch (+ the ladder's re-runs), not one per range
+
+
 def test_two_contexts_interleaved_on_one_thread(tmp_path, golden, monkeypatch):
     """Two live contexts on two (virtual) devices driven by ONE host thread in interleaved order -- create A, create B,
     chunks into A, chunks into B, search B, search A, top-r A, more chunks into B, search B: every entry point has to make

@@ -123,6 +123,35 @@ def test_titles_lookup(small, golden):
     assert t == [lines[i][1:] for i in idx]
 
 
+def test_titles_through_the_offset_sidecar(small, tmp_path):
+    """<prefix>.didx (written by preprocess beside the reference's three files: "SWIMDIDX", N, size of .desc, N line offsets) turns a
+    report's title lookups into positioned reads (load_database_headers reads all N, sequences.c:757-761); without it, or with a
+    stale / damaged one, the file is walked -- the titles are the same either way."""
+    import shutil
+    import struct
+    raw = open(small["prefix"] + ".didx", "rb").read()
+    magic, n, size = struct.unpack("<QQQ", raw[:24])
+    assert magic == int.from_bytes(b"SWIMDIDX", "little") and n == small["n"] and size == os.path.getsize(small["prefix"] + ".desc")
+    off = np.frombuffer(raw[24:], dtype=np.uint64)
+    desc = open(small["prefix"] + ".desc", "rb").read()
+    assert len(off) == n and off[0] == 0 and all(desc[int(o) - 1:int(o)] == b"\n" for o in off[1:]) and desc[int(off[-1]):].count(b"\n") == 1
+    idx = np.array([small["n"] - 1, 0, 17, 17, small["n"] // 2], dtype=np.int64)
+    want = [desc.split(b"\n")[i][1:].decode("latin1") for i in idx]
+    assert host.db_titles(small["prefix"], small["n"], idx) == want
+    # the same database without the sidecar, with one that names another .desc size, and with a truncated one: the walk answers
+    for k, damage in enumerate((None, "size", "short")):
+        p = str(tmp_path / f"db{k}")
+        for ext in (".desc", ".info", ".seq"):
+            shutil.copy(small["prefix"] + ext, p + ext)
+        if damage == "size":
+            open(p + ".didx", "wb").write(raw[:16] + struct.pack("<Q", size + 1) + raw[24:])
+        elif damage == "short":
+            open(p + ".didx", "wb").write(raw[:-8])
+        assert host.db_titles(p, small["n"], idx) == want, damage
+    with pytest.raises(host.SwimmHostError):
+        host.db_titles(small["prefix"], small["n"], np.array([small["n"]], dtype=np.int64))
+
+
 def test_ragged_and_edge_inputs(tmp_path):
     """CRLF, blank lines, lower case, one-residue and empty records, no trailing newline"""
     fa = tmp_path / "odd.fa"

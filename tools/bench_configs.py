@@ -21,6 +21,9 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from swimm_amd import hip_backend, host, submat, synth  # noqa: E402
 
+if os.environ.get("SWIMM_HIP_LIB"):      # (A/B against an older build of the library: it may lack the newest entry points)
+    hip_backend.ABI_SYMBOLS = tuple(n for n in hip_backend.ABI_SYMBOLS if n not in ("swimm_hip_device_pci_bus_id", "swimm_hip_bind_host_thread"))
+
 from swimm_amd import workloads  # noqa: E402
 
 CFG = workloads.CONFIGS

@@ -21,15 +21,15 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def kernels(path):
     txt = open(path).read()
     out = []
-    for m in re.finditer(r"\n(_ZN5swimm\d+(sw_\w+?_kernel)(\w*)):[^\n]*\n(.*?)s_endpgm(.*?)\.end_amdhsa_kernel", txt, re.S):
+    for m in re.finditer(r"\n(_ZN5swimm\d+((?:sw_|retile|tile_sequences|publish_items)\w*?_kernel)(\w*)):[^\n]*\n(.*?)s_endpgm(.*?)\.end_amdhsa_kernel", txt, re.S):
         sym, kind, rest, body, meta = m.groups()
         rec = {"symbol": sym, "kernel": kind,
                "vgprs": int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)),
                "scratch_bytes": int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)),
                "instructions": sum(1 for l in body.split("\n") if l.startswith("\t") and not l.lstrip().startswith((";", ".")))}
-        t = re.match(r"ILi(\d+)ELi(\d)ELb(\d)ELb(\d)E", rest)
+        t = re.match(r"ILi(\d+)ELi(\d)ELb(\d)ELb(\d)ELb(\d)E", rest)
         if kind == "sw_pipe_kernel" and t:
-            rec.update(rows_per_wave=int(t.group(1)), mode=int(t.group(2)), dynamic=t.group(3) == "1", group_resident=t.group(4) == "1",
+            rec.update(rows_per_wave=int(t.group(1)), mode=int(t.group(2)), dynamic=t.group(3) == "1", group_resident=t.group(4) == "1", growing_list=t.group(5) == "1",
                        v_perm_b32=len(re.findall(r"\bv_perm_b32", body)), v_pk_fma_f16=len(re.findall(r"\bv_pk_fma_f16", body)),
                        shifts_by_16=len(re.findall(r"v_lshrrev_b32_e32 v\d+, 16, v\d+", body)))
         t = re.match(r"ILi(\d)ELi(\d+)E", rest)

@@ -32,6 +32,12 @@ void ensure_cuts(swimm_hip_ctx *c)
         const GroupDesc &gd = c->groups[g];
         c->cut_cols[g] = gd.ncols;
         if (c->opt_cut <= 0 || (size_t)gd.seq0 + kGroupSeqs > c->seq_len.size()) continue;
+        // (a cut must save 3 % of the group's padded cells at least: a group whose FIRST pair is within 3 % of its longest member has
+        // nothing to cut -- nearly every group of a length-sorted database; two reads instead of 128)
+        {
+            const uint32_t l0 = std::max(c->seq_len[gd.seq0], c->seq_len[gd.seq0 + 1]);
+            if ((double)l0 >= 0.97 * (double)gd.ncols - kChunkCols) continue;
+        }
         uint32_t L[64];
         int last = -1;                                 // the last pair that holds a sequence (the database's last group is seldom full)
         bool sorted = true;
@@ -260,6 +266,42 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
     return 0;
 }
 
+// The launch shape of a streaming search's ONE launch over the growing item list (search.cpp, layout_ranges): one pass must hold
+// the query, and the workgroups -- resident for the whole search, waiting with all their registers whenever the link is behind --
+// must leave a tiling wave its registers on EVERY SIMD: the upload stream's tiling kernels have to run beside them on the same
+// CUs (workgroups are dealt to shader engines before a free CU is looked for; tools/microbench/spin_probe: beside 248
+// register-full workgroups on 256 CUs a newcomer waits for the launch to end, with registers to spare on every CU it runs at
+// once).  Registers: read from the code object of the growing-list instantiation.  Cost: padded rows over the shape's measured rate.
+int choose_one_list_plan(swimm_hip_ctx *c, int m, QueryPlan *out, int *n_wg_out)
+{
+    const int kTilingRegs = 32;
+    double best = -1;
+    for (int ti = 7; ti >= 0; --ti) {
+        const int T = 8 + 4 * ti;
+        if ((c->opt_T && T != c->opt_T) || !pipe_has_variant(Mode::F16, T)) continue;
+        int regs = 0;
+        if (grow_kernel_attributes(T, &regs) != hipSuccess) continue;
+        const int alloc = (regs + 7) / 8 * 8;
+        int maxW = T > 28 ? 12 : 16;
+        if (c->opt_maxW > 0) maxW = std::min(maxW, c->opt_maxW);
+        const int strips = std::max(1, (m + T - 1) / T);
+        for (int W = strips; W <= maxW; ++W) {
+            if (c->opt_W > 0 && W != std::min(c->opt_W, maxW)) continue;
+            const int nominal = std::max(1, std::min(4 * regs_to_waves_per_simd(regs) / W, (int)(163840 / pipe_lds_bytes(Mode::F16, T, W, false))));
+            int per_cu = nominal;
+            while (per_cu > 0 && alloc * ((per_cu * W + 3) / 4) > 512 - kTilingRegs) --per_cu;
+            if (per_cu == 0) continue;
+            const double cost = (double)(T * W) / (shape_gcups(T, W) * per_cu / nominal);
+            if (best < 0 || cost < best * (1.0 - 1e-9)) {
+                best = cost;
+                out->T = T; out->W = W; out->passes = 1; out->mpad = (uint32_t)(T * W); out->est_s = 0;
+                *n_wg_out = n_workgroups(c, per_cu);
+            }
+        }
+    }
+    return best < 0 ? 1 : 0;
+}
+
 // upper bound of the profile elements of a query batch (25 codes x rows padded to at most 16 x 36 and to the lane kernel's 512)
 uint64_t prof_elems_bound(const uint16_t *qm, uint32_t qn)
 {
@@ -423,6 +465,12 @@ std::vector<uint8_t> pick_tail(const swimm_hip_ctx *c, const Range &rg)   // -> 
     std::vector<uint8_t> is_tail(n, 0);
     if (c->opt_tail_mode == 2) return is_tail;                        // never
     if (c->opt_tail_mode == 1) { std::fill(is_tail.begin(), is_tail.end(), 1); return is_tail; }   // always
+    {   // no group is longer than the threshold for the WHOLE range's mean load (the loop below only ever compares with a smaller
+        // mean): no tail, and no need to sort -- every length-sorted database of ordinary proteins leaves here
+        uint32_t longest = 0;
+        for (uint32_t i = 0; i < n; ++i) longest = std::max(longest, bulk_cols(c, rg.g0 + i));
+        if ((double)longest <= c->opt_tail_frac * 0.01 * (double)rg.cols / c->num_cu) return is_tail;
+    }
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
     // (a group counts with the columns the pipeline kernel would align: its outlier pairs are lane-systolic items anyway)

@@ -376,6 +376,7 @@ struct SearchRun {
     bool one_list = false, one_list_launched = false;
     bool stalled = false;                   // ... its workgroups gave up waiting for the database (drain): the caller searches the resident copy
     QueryPlan one_list_qp;
+    int one_list_wg = 0;
     uint32_t one_list_items = 0;
     uint64_t one_list_chunks = 0;
     std::vector<uint8_t> range_pp;          // streaming: ranges that run like a resident database (launch shapes per query, one launch per pass, tail kernels)
@@ -442,7 +443,10 @@ int SearchRun::plan_for(size_t ri, int T, int W, bool resident, bool whole_db, D
         DbPlan &dp = stream_plans[ri][key];
         bool exact = true;
         for (size_t ci = range_chunks[ri].first; ci < range_chunks[ri].second; ++ci) exact = exact && c->chunks[up_order[ci].chunk].lens_known;
-        if (make_db_plan(c, main_mode, n_wg, no_tail, ranges[ri], exact, dp)) return 1;
+        g_list_arena = &c->list_arena;       // (no hipMalloc while kernels run: the lists come out of the arena sized in layout_ranges)
+        const int rc = make_db_plan(c, main_mode, n_wg, no_tail, ranges[ri], exact, dp);
+        g_list_arena = nullptr;
+        if (rc) return 1;
         *out = &dp;
     } else {
         *out = &it->second;
@@ -605,14 +609,47 @@ int SearchRun::layout_ranges()
             up_order.push_back(pt);
         }
     }
-    const size_t np = up_order.size();
     // ONE query that one pass of one workgroup shape holds: one launch over one item list that grows as the parts land.
     one_list = false;
     QueryPlan one_qp{};
     if (qn == 1 && c->opt_dynamic && main_mode == Mode::F16 && c->opt_resident != 1 && (int)qm[0] < c->opt_sp_threshold && c->groups.size() < 0x7FFFFFF0ull &&
-        choose_plan(c, main_mode, qm[0], false, true, &one_qp) == 0) {
+        choose_one_list_plan(c, qm[0], &one_qp, &one_list_wg) == 0) {
         one_list = true;
         one_list_qp = one_qp;
+        // A part costs that launch nothing but a publication (no launch per range any more), so the parts are FINE: the first
+        // ones 4, 8, 16 MiB -- the workgroups have their first items 0.2 ms after the call -- then at most 32 MiB each: what has
+        // crossed the link is aligned a millisecond later, not when the rest of a 96 MiB chunk has followed.
+        std::vector<UploadPart> fine;
+        uint64_t next_cap = (uint64_t)4 << 20;
+        for (const UploadPart &pt : up_order) {
+            const ChunkRec &r = c->chunks[pt.chunk];
+            bool ascending = !r.uploaded && r.groups_uploaded == 0;
+            if (r.kind == 0 && ascending)
+                for (uint32_t v = 1; v < r.group_count; ++v) ascending = ascending && r.h_disp[v] >= r.h_disp[v - 1];
+            if (!ascending) { fine.push_back(pt); continue; }          // (a caller's layout whose groups do not lie in order travels whole)
+            // in the direction the database travels: a chunk's own groups longest first when it descends
+            uint32_t lo = pt.g0, hi = pt.g1;
+            while (lo < hi) {
+                uint64_t acc = 0;
+                uint32_t a = lo, b = hi;
+                if (descending) { a = hi; while (a > lo && (acc < next_cap || a - lo < 8)) { --a; acc += (uint64_t)r.gcols[a] * kGroupSeqs; } b = hi; hi = a; }
+                else { b = lo; while (b < hi && (acc < next_cap || hi - b < 8)) { acc += (uint64_t)r.gcols[b] * kGroupSeqs; ++b; } a = lo; lo = b; }
+                UploadPart sub = pt;
+                sub.g0 = a; sub.g1 = b;
+                sub.ready = (descending ? a == pt.g0 : b == pt.g1) ? pt.ready : nullptr;      // (the chunk's / head part's event marks its LAST sub-part)
+                if (!sub.ready) {
+                    while (c->part_ev.size() <= n_part_ev) {
+                        hipEvent_t e;
+                        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                        c->part_ev.push_back(e);
+                    }
+                    sub.ready = c->part_ev[n_part_ev++];
+                }
+                fine.push_back(sub);
+                next_cap = std::min<uint64_t>(next_cap * 2, (uint64_t)32 << 20);
+            }
+        }
+        up_order.swap(fine);
         std::vector<Item> items;
         items.reserve(c->groups.size());
         std::vector<uint32_t> order;
@@ -642,6 +679,7 @@ int SearchRun::layout_ranges()
         (void)hipGetLastError();
         g_err.clear();
     }
+    const size_t np = up_order.size();
     if (ensure_uploader(c)) return 1;
     c->up->post(up_order);
     if (dbg) fprintf(stderr, "swimm_hip: upload order laid out (%zu parts%s), uploader started %.3f ms after the call began\n", np, one_list ? ", one item list" : "", (now_s() - t_begin) * 1e3);
@@ -684,6 +722,28 @@ int SearchRun::layout_ranges()
         range_chunks.push_back({first, i});
     }
     stream_plans.resize(ranges.size());
+    {   // the arena the ranges' work lists are carved from: per range and launch-shape class three item lists (32 B per group each)
+        // and the workgroup tables; a handful of classes per range (distinct workgroup counts x with / without tail)
+        const size_t classes = std::min<size_t>(qn, 6) + 2;
+        size_t need = (size_t)c->groups.size() * 3 * sizeof(Item) * classes + ranges.size() * classes * ((size_t)c->num_cu * 4 * 8 + 4096) + ((size_t)4 << 20);
+        need += (size_t)c->groups.size() / 8 * 64 * sizeof(LaneItem);           // lane-systolic tails: a minority of groups, 64 pairs each
+        if (c->list_arena.cap < need) {
+            if (c->list_arena.base) HIP_TRY(hipFree(c->list_arena.base));
+            c->list_arena = DevArena{};
+            HIP_TRY(hipMalloc((void **)&c->list_arena.base, need));
+            c->list_arena.cap = need;
+        }
+        c->list_arena.used = 0;
+        // ... and the pinned buffer the lists travel through (list_copy) holds the largest single list, now, not by growing mid-search
+        const size_t pin_need = (size_t)c->groups.size() * sizeof(Item) + ((size_t)1 << 20);
+        if (c->pin_cap < pin_need) {
+            HIP_TRY(hipStreamSynchronize(list_stream(c)));
+            if (c->pin) { HIP_TRY(hipHostFree(c->pin)); c->pin = nullptr; c->pin_cap = 0; }
+            HIP_TRY(hipHostMalloc(&c->pin, pin_need, hipHostMallocDefault));
+            c->pin_cap = pin_need;
+            c->pin_used = 0;
+        }
+    }
     return 0;
 }
 
@@ -1315,17 +1375,9 @@ int SearchRun::issue()
 int SearchRun::issue_one_list()
 {
     const QueryPlan &qp = qps[0];
-    // Workgroups: what the chip holds of THIS instantiation -- less a few CUs' worth.  These workgroups stay until the list is
-    // exhausted, waiting (registers and all) whenever the link is behind; the tiling kernels of the parts still to come must
-    // find a place to run meanwhile, whatever the pipeline kernel's register count leaves free on a CU.
-    int regs = 0;
-    HIP_TRY(grow_kernel_attributes(qp.T, &regs));
-    const int per_cu = std::max(1, std::min(4 * regs_to_waves_per_simd(regs) / qp.W, (int)(163840 / pipe_lds_bytes(main_mode, qp.T, qp.W, false))));
-    const int kTilingCUs = getenv("SWIMM_HIP_EXP_TILING_CUS") ? atoi(getenv("SWIMM_HIP_EXP_TILING_CUS")) : 8;
-    const int cus = c->num_cu > 4 * kTilingCUs ? c->num_cu - kTilingCUs : c->num_cu;
-    int n_wg = cus * per_cu;
-    if (c->opt_wg_limit > 0) n_wg = std::min(n_wg, c->opt_wg_limit);
-    n_wg = (int)std::min<uint32_t>((uint32_t)n_wg, one_list_items);
+    // (the shape and the workgroup count come from choose_one_list_plan: what the chip holds of the growing-list instantiation
+    // while every SIMD keeps a tiling wave's registers free)
+    const int n_wg = (int)std::min<uint32_t>((uint32_t)one_list_wg, one_list_items);
     if (list_sync(c)) return 1;                                   // the item list has arrived (copied while the plans were made)
     if (c->queue_next >= c->d_queue.cap) return fail("pipeline launch cursors exhausted");
     PipeParams p{};

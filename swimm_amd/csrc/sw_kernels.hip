@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(T > 28 ? 768 : 1024) sw_pipe_kernel(const Pipe
                         // height (profiles/r03_plan_sweep.txt): unfenced up to 24 rows; the taller strips gain from a fence after every group of 4
                         // rows (28 rows: 8 620 -> 10 220 GCUPS -- unfenced it spills; 32 rows: 10 100 -> 10 450 and 16 fewer registers, a fourth wave
                         // per SIMD), 36 rows from one after every other group.
-                        constexpr int kFence = (T == 28 || T == 32) ? 1 : T == 36 ? 2 : 0;
+                        constexpr int kFence = (T == 28 || T == 32 || (GROW && T == 24)) ? 1 : T == 36 ? 2 : 0;      // (GROW, 24 rows: fenced to fit 120 registers, see launch_grow)
                         if (kFence && (g + 1) % (kFence ? kFence : 1) == 0 && g + 1 < T / 4) __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {

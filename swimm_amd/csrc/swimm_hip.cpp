@@ -12,6 +12,7 @@
 
 thread_local std::string swimm_impl::g_err;
 thread_local int swimm_impl::g_cur_vdevice = -1;
+thread_local swimm_impl::DevArena *swimm_impl::g_list_arena = nullptr;
 
 extern "C" {
 
@@ -77,21 +78,6 @@ int swimm_hip_bind_host_thread(int device, int num_devices, char *cpulist_out, s
     return 0;
 }
 
-// (experiment knob SWIMM_HIP_EXP_UPSTREAM: 0 = a plain stream, 1 = high priority, 2 = a stream with a CU mask of all CUs, which
-// the runtime backs with a hardware queue of its own)
-static hipError_t create_upload_stream(hipStream_t *s, int prio_high, int num_cu)
-{
-    const char *e = getenv("SWIMM_HIP_EXP_UPSTREAM");
-    const int how = e ? atoi(e) : 1;
-    if (how == 0) return hipStreamCreate(s);
-    if (how == 2) {
-        std::vector<uint32_t> mask((size_t)(num_cu + 31) / 32, 0xFFFFFFFFu);
-        if (num_cu % 32) mask.back() = (1u << (num_cu % 32)) - 1u;
-        return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
-    }
-    return hipStreamCreateWithPriority(s, hipStreamDefault, prio_high);
-}
-
 int swimm_hip_create(int device, swimm_hip_ctx **out)
 {
     if (!out) return fail("swimm_hip_create: out is NULL");
@@ -111,16 +97,10 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     c->vdevice = vdevice;
     g_cur_vdevice = vdevice;
     c->num_cu = prop.multiProcessorCount;
-    // The upload stream gets a HIGH priority: not for the priority's sake -- HIP keeps the hardware queues of every priority
-    // class apart, and multiplexes the streams of one class onto four of them.  The upload stream must never share a hardware
-    // queue with a stream that runs DP kernels: its tiling kernels would wait in that queue behind a persistent pipeline
-    // launch which (in a search that streams its database in, PipeParams::avail) is itself waiting for the tiled data.
-    int prio_low = 0, prio_high = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream_b) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
-        create_upload_stream(&c->stream_up, prio_high, c->num_cu) != hipSuccess || hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreate(&c->stream_up) != hipSuccess || hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess) {
@@ -158,7 +138,8 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     swimm_hip_clear_db(c);
     pool_trim(c);
     for (hipEvent_t e : c->part_ev) (void)hipEventDestroy(e);
-    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_avail.release(); c->d_stream_items.release(); c->d_qcodes.release(); c->d_sub16.release(); c->d_qdesc.release(); c->d_wave_out.release();
+    c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_avail.release(); c->d_stream_items.release();
+    if (c->list_arena.base) { (void)hipFree(c->list_arena.base); c->list_arena = DevArena{}; } c->d_qcodes.release(); c->d_sub16.release(); c->d_qdesc.release(); c->d_wave_out.release();
     if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = c->pin_used = 0; }
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_t[0].release(); c->tail_scratch_t[1].release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release(); c->d_ladder_counts.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);

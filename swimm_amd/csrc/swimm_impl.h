@@ -51,19 +51,46 @@ inline double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// A search that streams its database in builds work lists per range WHILE kernels run -- and a hipMalloc issued then was
+// measured to wait for the running launch (c4: 48 ms inside make_db_plan, and the uploader's next copy stuck behind it).  Such
+// lists are carved out of one arena the context owns, sized before the search's first launch (SearchRun::layout_ranges);
+// the thread that builds them names the arena here and DevBuf::reserve takes from it.
+struct DevArena {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+    void *take(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (!base || used + bytes > cap) return nullptr;
+        void *q = base + used;
+        used += bytes;
+        return q;
+    }
+};
+extern thread_local DevArena *g_list_arena;
+
 template <class T>
 struct DevBuf {   // grow-only device scratch
     T *p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;      // p lies in an arena: nothing to free
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        if (g_list_arena) {
+            if (void *q = g_list_arena->take(n * sizeof(T))) {
+                if (p && !borrowed) (void)hipFree(p);
+                p = (T *)q; cap = n; borrowed = true;
+                return hipSuccess;
+            }
+        }
+        if (p && !borrowed) { hipError_t e = hipFree(p); if (e != hipSuccess) { p = nullptr; cap = 0; return e; } }
+        p = nullptr; cap = 0; borrowed = false;
         hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
         if (e == hipSuccess) cap = n;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
 };
 
 // the lengths of a run of bulk groups, longest first, with the makespan factors already worked out for it
@@ -223,6 +250,7 @@ struct swimm_hip_ctx {
     hipEvent_t ev_avail = nullptr;      // ... its count has been reset (on the upload stream)
     DevBuf<uint32_t> d_avail;           // streaming search with one item list: how many of its items have landed (publish_items_kernel)
     DevBuf<Item> d_stream_items;        // ... and that list (every group of the database, in the order the parts travel)
+    DevArena list_arena;                // work lists of the ranges of a streaming search (DevArena above)
     DevBuf<uint32_t> d_queue;           // one cursor per pipeline launch of a search
     uint32_t queue_next = 0;
     // queries (host copies; profiles are built per search because T/W may change)
@@ -393,6 +421,7 @@ void bulk_cols_of(const swimm_hip_ctx *c, const Range &rg, BulkCols &b);
 double plan_imbalance(swimm_hip_ctx *c, int n_wg);
 int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bool overlapped, QueryPlan *out,
                 const Range *rg = nullptr, BulkCols *rb = nullptr);
+int choose_one_list_plan(swimm_hip_ctx *c, int m, QueryPlan *out, int *n_wg_out);
 double shape_gcups(int T, int W);      // measured rate of a launch shape of the f16-tier pipeline kernel (GCUPS of padded cells)
 uint64_t prof_elems_bound(const uint16_t *qm, uint32_t qn);
 int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_t qn, std::vector<QueryPlan> &qps);

@@ -126,7 +126,7 @@ int swimm_hip_last_plan(swimm_hip_ctx *ctx, uint32_t q, int *rows_per_wave, int 
 int swimm_hip_last_launch_ms(swimm_hip_ctx *ctx, double *sum_ms, uint32_t *launches);
 
 /* Name of the dominant DP kernel of that plan, as the code object carries it and rocprofv3 lists it (demangled, e.g.
- * "void swimm::sw_pipe_kernel<24, 2, true>(swimm::PipeParams)"), so that a profile can be matched to a search
+ * "void swimm::sw_pipe_kernel<24, 2, true, false, false>(swimm::PipeParams)"), so that a profile can be matched to a search
  * without guessing.  Measurement aid only (row (d) of SURVEY.md section 8); no reference counterpart. */
 int swimm_hip_last_kernel_name(swimm_hip_ctx *ctx, uint32_t q, char *buf, size_t buf_len);
 

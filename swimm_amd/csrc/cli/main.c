@@ -276,7 +276,7 @@ static void fold_lists(int32_t *run_s, int64_t *run_i, const int32_t *part_s, co
 
 typedef struct {
     const swimm_hip_api *api; const swimm_options *o; const swimm_queries *q; const char *submat; const swimm_db *db;
-    work_queue *wq; int device, devices, index; unsigned long top; double tick; uint64_t min_slab;
+    work_queue *wq; int device, index; unsigned long top; double tick; uint64_t min_slab;
     int32_t *run_s; int64_t *run_i;          /* [query][top], global indices */
     uint64_t sequences, claims, promoted; double kernel_ms, end_s; char err[512];
 } gpu_worker;
@@ -289,7 +289,9 @@ static void *gpu_worker_main(void *p)
     swimm_hip_ctx *ctx = NULL;
     int32_t *ps = (int32_t *)malloc(q->count * w->top * sizeof(int32_t));
     int64_t *pi = (int64_t *)malloc(q->count * w->top * sizeof(int64_t));
-    (void)api->bind_host_thread(w->device, w->devices, NULL, 0);   /* (and the context's uploader thread; best effort) */
+    /* (no CPU binding here, unlike mode 1: the host leg's OpenMP team runs on every core the process has, and a device worker
+     * -- its uploader thread copies out of pageable memory -- is better off wherever the kernel finds it a free hardware thread
+     * than pinned among spinning OpenMP threads: measured, the GPU leg of the 400 000-sequence test ended 28 % after the host's) */
     int bad = api->create(w->device, &ctx);
     if (!bad) bad = api->set_option(ctx, "lazy_upload", 1);     /* the slab streams in piece by piece while the search runs */
     if (!bad) bad = api->set_option(ctx, "sp_threshold", sp_threshold_of(w->o));
@@ -351,7 +353,7 @@ static void hybrid_search(const swimm_hip_api *api, const swimm_options *o, cons
     const double tick = swimm_wtime();
     for (int i = 0; i < NW; ++i) {
         gpu_worker *w = &gw[i];
-        w->api = api; w->o = o; w->q = q; w->submat = submat; w->db = db; w->wq = &wq; w->device = i % G; w->devices = G; w->index = i; w->top = top; w->tick = tick; w->min_slab = min_slab;
+        w->api = api; w->o = o; w->q = q; w->submat = submat; w->db = db; w->wq = &wq; w->device = i % G; w->index = i; w->top = top; w->tick = tick; w->min_slab = min_slab;
         w->run_s = (int32_t *)malloc(list * sizeof(int32_t)); w->run_i = (int64_t *)malloc(list * sizeof(int64_t));
         for (size_t k = 0; k < list; ++k) { w->run_s[k] = -1; w->run_i[k] = -1; }
         if (pthread_create(&th[i], NULL, gpu_worker_main, w)) { printf("SWIMM: cannot start a GPU thread.\n"); exit(1); }

@@ -91,12 +91,8 @@ int wgs_per_cu(const swimm_hip_ctx *c, Mode mode, int T, int W, bool resident, i
 // a query of several passes runs the group-resident kernel (one launch) unless that is switched off
 bool resident_for(const swimm_hip_ctx *c, int passes) { (void)passes; return c->batch_now; }
 
-// a run of consecutive device groups that is searched as one unit: the whole resident database (work lists cached),
-// or one chunk of a database that is still streaming in
-// Work lists travel on the upload stream -- except while a search streams its database in: the upload stream then
-// belongs to the uploader thread's chunk copies (0.1 GB each), and the lists take the promotion stream, idle until
-// the ladder at the end of the search.
-hipStream_t list_stream(const swimm_hip_ctx *c) { return c->streaming_now ? c->stream3 : c->stream_up; }
+// Work lists travel on a stream of their own (not behind the uploader's chunk copies, not behind the promotion ladder)
+hipStream_t list_stream(const swimm_hip_ctx *c) { return c->stream_list; }
 
 // ... and through a pinned arena: a copy from pageable memory would queue for the runtime's staging buffers behind
 // the uploader's chunk copies (measured: 1.2 ms per range's lists instead of 0.3).  list_sync() ends a batch of copies.
@@ -230,11 +226,15 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
             if (overlapped && passes != 1) continue;   // only one-pass queries take part in the rotation
             int per_cu = 1;
             if (wgs_per_cu(c, mode, T, W, resident_for(c, passes), &per_cu)) return 1;
-            if (room_for_lane_waves && !c->opt_T) {
+            // registers that must stay free on every SIMD: 80 for a lane-systolic wave; 32 for the tiling waves of a database
+            // that is still streaming in (c->tiling_room: a launch whose workgroups fill the register file holds the upload
+            // stream's tiling kernels -- and the copies queued behind them -- back for as long as it runs)
+            const int keep = std::max(room_for_lane_waves ? 80 : 0, c->tiling_room ? 32 : 0);
+            if (keep && !c->opt_T) {
                 int regs = 0;
                 if (kernel_regs(c, mode, T, resident_for(c, passes), &regs)) return 1;
                 const int alloc = (regs + 7) / 8 * 8;
-                if (alloc * ((per_cu * W + 3) / 4) > 512 - 80) continue;
+                if (alloc * ((per_cu * W + 3) / 4) > 512 - keep) continue;
             }
             // seconds: every pass aligns T x W rows against the whole resident database at the shape's rate, and costs
             // a launch (pipeline fill and drain, staging, the last workgroups running alone: ~0.15 ms, which is what
@@ -262,6 +262,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
     }
     // (no admissible shape leaves a lane-systolic wave its registers, e.g. under a max_waves cap: the tail then shares)
     if (best_cost < 0 && room_for_lane_waves) return choose_plan(c, mode, m, false, overlapped, out, rg, rb);
+    if (best_cost < 0 && c->tiling_room) { c->tiling_room = false; const int rc = choose_plan(c, mode, m, false, overlapped, out, rg, rb); c->tiling_room = true; return rc; }
     if (best_cost < 0) { fail("no kernel variant for rows_per_wave=%d waves=%d", c->opt_T, c->opt_W); return 1; }
     return 0;
 }
@@ -332,6 +333,11 @@ int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_
         if (c->opt_T && T != c->opt_T) continue;
         if (!pipe_has_variant(mode, T)) continue;
         Wof[ti] = c->opt_W > 0 ? std::min(c->opt_W, T > 28 ? 12 : 16) : std::min(4, c->opt_maxW > 0 ? c->opt_maxW : 4);
+        if (c->tiling_room && !c->opt_T) {          // (a database that is still streaming in: see choose_plan)
+            int regs = 0, per_cu = 1;
+            if (kernel_regs(c, mode, T, true, &regs) || wgs_per_cu(c, mode, T, Wof[ti], true, &per_cu)) return 1;
+            if ((regs + 7) / 8 * 8 * ((per_cu * Wof[ti] + 3) / 4) > 512 - 32) continue;
+        }
         ok[ti] = true;
         for (uint32_t q = 0; q < qn; ++q) cost[ti] += rows_of(qm[q], T, Wof[ti]) / rate_of(ti, Wof[ti]);
     }

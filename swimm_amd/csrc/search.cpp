@@ -526,6 +526,7 @@ int SearchRun::begin(uint64_t *slots_out)
     qdisp = c->qdisp.data() + qb;
     S = (uint64_t)c->groups.size() * kGroupSeqs;
     *slots_out = S;
+    c->tiling_room = false;
     // (binary16 first tier: results below f16_exact_below(extend) are exact -- the pipeline kernel's column offsets take up to 127 of the
     // 2048; with an extend penalty beyond 237 the tier would be exact below 1 100 only, and the int16 tier is the first)
     main_mode = c->opt_force_i32 ? Mode::I32 : (c->opt_f16 && f16_exact_below(c->extend_gap) >= 1100 ? Mode::F16 : Mode::PK16);
@@ -754,12 +755,14 @@ int SearchRun::plan_queries()
     // query's end are zero, like the reference's dummy row 23
     range_pp.assign(ranges.size(), 0);
     alternate_pp = false;
+    c->tiling_room = streaming;            // launch shapes of a database that is still landing leave the tiling waves their registers
     if (one_list) {          // one query, one pass, one launch over the whole database as it lands (layout_ranges)
         qps.assign(1, one_list_qp);
         rotated.assign(1, 0); use_sp.assign(1, 0); in_batch.assign(1, 0); stack_of.assign(1, -1);
         stacks.clear();
         lane_room = cut_room = many_short = alternate = false;
         c->batch_now = false;
+        c->tiling_room = false;
         const uint32_t lane_rows = (uint32_t)((qm[0] + 64 * kLaneRows - 1) / (64 * kLaneRows) * (64 * kLaneRows));     // (the promotion re-runs read the same profile)
         qps[0].mpad = std::max(qps[0].mpad, lane_rows);
         qps[0].prof_off = 0;
@@ -921,7 +924,10 @@ int SearchRun::plan_queries()
             for (size_t ri = 0; ri < ranges.size(); ++ri) {
                 if (rqps[ri].empty()) continue;
                 if (use_sp[q]) { rqps[ri][q] = qps[q]; continue; }
-                if (choose_plan(c, main_mode, qm[q], room, false, &rqps[ri][q], &ranges[ri], &rbulk[ri])) return 1;
+                c->tiling_room = streaming && ri + 1 < ranges.size();       // (the last range's launches start when everything has landed)
+                const int rc_plan = choose_plan(c, main_mode, qm[q], room, false, &rqps[ri][q], &ranges[ri], &rbulk[ri]);
+                c->tiling_room = streaming;
+                if (rc_plan) return 1;
                 qps[q].mpad = std::max(qps[q].mpad, rqps[ri][q].mpad);
                 if (dbg) fprintf(stderr, "swimm_hip:   range %zu: T=%d W=%d passes=%d\n", ri, rqps[ri][q].T, rqps[ri][q].W, rqps[ri][q].passes);
             }
@@ -951,6 +957,7 @@ int SearchRun::plan_queries()
                          (unsigned long long)ranges.back().cols, alternate_pp ? ", queries alternating on two streams" : "");
     }
     c->batch_now = any_batch;
+    c->tiling_room = false;
     return 0;
 }
 

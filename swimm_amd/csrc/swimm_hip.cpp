@@ -98,6 +98,7 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     g_cur_vdevice = vdevice;
     c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream_b) != hipSuccess ||
+        hipStreamCreate(&c->stream_list) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreate(&c->stream_up) != hipSuccess || hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming) != hipSuccess ||
@@ -155,6 +156,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
+    if (c->stream_list) (void)hipStreamDestroy(c->stream_list);
     if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);
     if (c->ev_avail) (void)hipEventDestroy(c->ev_avail);
     c->up_b.release(); c->up_n.release(); c->up_disp.release(); c->up_gcols.release(); c->up_off.release(); c->up_goff.release();

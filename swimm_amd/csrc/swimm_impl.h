@@ -205,7 +205,8 @@ struct swimm_hip_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     hipStream_t stream2 = nullptr;      // lane-systolic tail runs beside the bulk kernel
     hipEvent_t ev_tail = nullptr;
-    hipStream_t stream_up = nullptr;    // uploads: H2D copies, (re-)tile kernels, work lists -- never waits for a DP kernel
+    hipStream_t stream_up = nullptr;    // uploads: H2D copies, (re-)tile kernels -- never waits for a DP kernel
+    hipStream_t stream_list = nullptr;  // work lists (list_copy)
     hipEvent_t ev_copied = nullptr;
     DevBuf<uint8_t> up_b; DevBuf<uint16_t> up_n; DevBuf<uint32_t> up_disp, up_gcols, up_off; DevBuf<uint64_t> up_goff;   // upload scratch, reused chunk after chunk
     int opt_upload_piece_kib = 98304;   // lazy_upload: chunks and slabs larger than this are recorded in pieces of about this size (96 MiB, the reference's chunk size)
@@ -227,6 +228,7 @@ struct swimm_hip_ctx {
     bool batch_now = false;             // the search in progress runs its non-rotated queries as group-resident batch launches
     std::vector<uint8_t> stream_tail;   // streaming search: the tail flags of the whole database (pick_tail)
     bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
+    bool tiling_room = false;           // ... and the launch shapes being chosen must leave the tiling waves their registers (plan.cpp, choose_plan)
     DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
     DevBuf<uint32_t> d_wave_out;        // stacks of short queries: per (stack, wave) the first element of the wave's member's score row
     int opt_cut = 35;                   // outlier pairs: a group's longest pairs leave it for the lane-systolic kernel when that saves the pipeline kernel more padded cells than opt_cut/10 x the pairs' own (0 = never)

@@ -92,7 +92,7 @@ def test_c4_long_query_envnr_shape():
         third, _ = s.search(chunks.vc * 128)
         assert s.last_stats()["launches"] >= 3 * s.last_plan(0)["passes"]
     chunks.close()
-    assert plan["passes"] >= 12 and name.endswith("true, true>(swimm::PipeParams)"), name
+    assert plan["passes"] >= 12 and name.endswith("true, true, false>(swimm::PipeParams)"), name
     assert np.array_equal(got, res) and np.array_equal(got, other) and np.array_equal(got, third)
     want, idx = oracle_matrix(w)
     _check_matrix(got[:, :w["n"]], want, idx, "c4")
@@ -259,7 +259,7 @@ def test_query_batch_group_resident_launch():
         s.set_option("resident", 0)
         other, _ = s.search(stride)
         st0 = s.last_stats()
-    assert name.endswith("true, true>(swimm::PipeParams)") and st["launches"] < 20 < st0["launches"], (name, st, st0)
+    assert name.endswith("true, true, false>(swimm::PipeParams)") and st["launches"] < 20 < st0["launches"], (name, st, st0)
     assert np.array_equal(got, other)
     want, idx = oracle_matrix(w)
     _check_matrix(got[:, :shard["n"]], want, idx, "query batch")

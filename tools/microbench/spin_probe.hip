@@ -52,6 +52,29 @@ __global__ void __launch_bounds__(1024) spin_kernel_fat(const uint32_t *flag, ui
     if (threadIdx.x == 0) { seen[2 * blockIdx.x] = v; seen[2 * blockIdx.x + 1] = polls + (acc == 12345.678f ? lds[5] : 0); }
 }
 
+// ... and shaped like a group-resident range launch: 256 threads, ~131 registers, 37 KB LDS, three per CU
+__global__ void __launch_bounds__(256) spin_kernel_res(const uint32_t *flag, uint32_t limit, uint32_t *seen, int heavy)
+{
+    __shared__ uint32_t lds[9472];      // 37 KB
+    float r[122];
+#pragma unroll
+    for (int i = 0; i < 122; ++i) r[i] = (float)(threadIdx.x + i * heavy);
+    lds[threadIdx.x] = threadIdx.x;
+    uint32_t v = 0, polls = 0;
+    if (threadIdx.x < 64) {
+        for (; polls < limit; ++polls) {
+            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (v) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    __syncthreads();
+    float acc = 0;
+#pragma unroll
+    for (int i = 0; i < 122; ++i) { asm volatile("" : "+v"(r[i])); acc += r[i] * (float)(v + i); }
+    if (threadIdx.x == 0) { seen[2 * blockIdx.x] = v; seen[2 * blockIdx.x + 1] = polls + (acc == 12345.678f ? lds[5] : 0); }
+}
+
 __global__ void work_kernel(uint32_t *buf, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) buf[i] = (uint32_t)i * 3u;
@@ -78,13 +101,17 @@ int main(int argc, char **argv)
     hipEventCreate(&eb); hipEventCreate(&ep);
     uint32_t *hbuf = (uint32_t *)malloc(n * 4);
     for (size_t i = 0; i < n; ++i) hbuf[i] = (uint32_t)i;
+    uint32_t *pinned = nullptr;
+    hipHostMalloc((void **)&pinned, 1 << 20, hipHostMallocDefault);
     hipDeviceSynchronize();
     const uint32_t limit = 400000;       // about half a second of polling
     const double t0 = now();
-    if (heavy == 2) hipLaunchKernelGGL(spin_kernel_fat, dim3(blocks), dim3(threads), 0, sa, flag, limit, seen, heavy);
+    if (heavy == 3) hipLaunchKernelGGL(spin_kernel_res, dim3(blocks), dim3(threads), 0, sa, flag, limit, seen, heavy);
+    else if (heavy == 2) hipLaunchKernelGGL(spin_kernel_fat, dim3(blocks), dim3(threads), 0, sa, flag, limit, seen, heavy);
     else hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(threads), 0, sa, flag, limit, seen, heavy);
     std::this_thread::sleep_for(std::chrono::milliseconds(5));      // A is resident and polling
-    if (h2d) hipMemcpyAsync(buf, hbuf, n * 4, hipMemcpyHostToDevice, sb);      // (pageable source, like the uploader's copies)
+    if (h2d == 1) hipMemcpyAsync(buf, hbuf, n * 4, hipMemcpyHostToDevice, sb);      // (pageable source, like the uploader's copies)
+    if (h2d == 2) { hipMemcpyAsync(buf, pinned, 1 << 20, hipMemcpyHostToDevice, sb); hipStreamSynchronize(sb); }      // (1 MB from pinned memory + a wait, like a work list)
     const double t_copy = now();
     hipLaunchKernelGGL(work_kernel, dim3(512), dim3(256), 0, sb, buf, n);
     hipEventRecord(eb, sb);
@@ -102,6 +129,6 @@ int main(int argc, char **argv)
     uint32_t max_polls = 0;
     for (int b = 0; b < blocks; ++b) { saw += hs[2 * b] != 0; if (hs[2 * b + 1] > max_polls) max_polls = hs[2 * b + 1]; }
     printf("A: %d x %d threads%s, second stream %s%s: copy call returned %.2f ms, B done %.2f ms, publish done %.2f ms, A done %.2f ms after A's launch; %d of %d workgroups saw the flag (most polls %u of %u)\n",
-           blocks, threads, heavy == 2 ? " x ~128 VGPRs + 96 KB LDS" : heavy ? " + 64 KB LDS" : "", prio ? "high priority" : "plain", h2d ? ", 32 MB pageable H2D first" : "", (t_copy - t0) * 1e3, (t_b - t0) * 1e3, (t_p - t0) * 1e3, (t_a - t0) * 1e3, saw, blocks, max_polls, limit);
+           blocks, threads, heavy == 3 ? " x ~131 VGPRs + 37 KB LDS" : heavy == 2 ? " x ~128 VGPRs + 96 KB LDS" : heavy ? " + 64 KB LDS" : "", prio ? "high priority" : "plain", h2d == 1 ? ", 32 MB pageable H2D first" : h2d == 2 ? ", 1 MB pinned H2D + wait first" : "", (t_copy - t0) * 1e3, (t_b - t0) * 1e3, (t_p - t0) * 1e3, (t_a - t0) * 1e3, saw, blocks, max_polls, limit);
     return 0;
 }

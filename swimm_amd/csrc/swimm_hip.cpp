@@ -210,7 +210,7 @@ static int add_chunk_piece(swimm_hip_ctx *c, const char *b, uint64_t vD, const u
     }
     rec.first_seq = first_group * vl;
     rec.n_seq = (uint64_t)group_count * vl;
-    if (register_chunk(c, rec, {})) return 1;
+    if (register_chunk(c, rec, nullptr, 0)) return 1;
     if (c->opt_lazy_upload ? ensure_uploader(c) : upload_chunk(c, c->chunks.back())) return 1;
     return 0;
 }
@@ -284,27 +284,33 @@ int swimm_hip_add_sequences(swimm_hip_ctx *c, const uint16_t *lengths, const cha
 
 static int add_sequences_piece(swimm_hip_ctx *c, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq)
 {
+    // (one walk over the lengths: residue offsets, every device group's longest member -- this runs inside the caller's
+    // "first search after a cold upload", 35 M sequences at the full Env-NR size)
     ChunkRec rec;
     rec.kind = 1;
     rec.off.resize(n_seq + 1);
-    uint64_t total = 0;
-    for (uint64_t i = 0; i < n_seq; ++i) { rec.off[i] = (uint32_t)total; total += lengths[i]; if (total > 0xFFFFFFF0ull) return fail("swimm_hip_add_sequences: slab larger than 4 GiB"); }
-    rec.off[n_seq] = (uint32_t)total;
-    if (ctx_enter(c)) return 1;
-    rec.h_codes = codes; rec.code_bytes = total;
     rec.n_groups = (uint32_t)((n_seq + kGroupSeqs - 1) / kGroupSeqs);
     rec.goff.resize(rec.n_groups);
     rec.gcols.resize(rec.n_groups);
+    uint64_t total = 0;
+    uint32_t *off = rec.off.data();
     for (uint32_t g = 0; g < rec.n_groups; ++g) {
         uint32_t mx = 1;
         const uint64_t e = std::min<uint64_t>(n_seq, (uint64_t)(g + 1) * kGroupSeqs);
-        for (uint64_t i = (uint64_t)g * kGroupSeqs; i < e; ++i) mx = std::max<uint32_t>(mx, lengths[i]);
+        for (uint64_t i = (uint64_t)g * kGroupSeqs; i < e; ++i) {
+            off[i] = (uint32_t)total;
+            total += lengths[i];
+            mx = std::max<uint32_t>(mx, lengths[i]);
+        }
+        if (total > 0xFFFFFFF0ull) return fail("swimm_hip_add_sequences: slab larger than 4 GiB");
         rec.gcols[g] = (mx + kChunkCols - 1) / kChunkCols * kChunkCols;
     }
+    off[n_seq] = (uint32_t)total;
+    if (ctx_enter(c)) return 1;
+    rec.h_codes = codes; rec.code_bytes = total;
     rec.first_seq = first_seq;
     rec.n_seq = n_seq;
-    std::vector<uint32_t> lens(lengths, lengths + n_seq);
-    if (register_chunk(c, rec, lens)) return 1;
+    if (register_chunk(c, rec, lengths, n_seq)) return 1;
     if (c->opt_lazy_upload ? ensure_uploader(c) : upload_chunk(c, c->chunks.back())) return 1;
     return 0;
 }

@@ -438,7 +438,7 @@ bool use_split(const swimm_hip_ctx *c, const QueryPlan &qp, const Plan &pl, size
 
 // ---- upload.cpp: chunks (upload_chunk is declared above, before the Uploader)
 int refresh_plans(swimm_hip_ctx *c);
-int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> &lens_or_empty);
+int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const uint16_t *lens_or_null, uint64_t n_lens);
 int ensure_uploader(swimm_hip_ctx *c);
 int sync_lengths(swimm_hip_ctx *c);
 int pool_alloc(swimm_hip_ctx *c, size_t bytes, void **out, size_t *cap);

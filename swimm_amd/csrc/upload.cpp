@@ -43,7 +43,7 @@ void pool_trim(swimm_hip_ctx *c)
 }
 
 // Registers a chunk's device groups (geometry only: nothing is copied here).
-int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> &lens_or_empty)
+int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const uint16_t *lens_or_null, uint64_t n_lens)
 {
     CHECK_DEVICE(c);
     const uint32_t dev_groups = rec.n_groups;
@@ -72,7 +72,7 @@ int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const std::vector<uint32_t> 
     }
     const size_t base = c->seq_len.size();
     c->seq_len.resize(base + (size_t)dev_groups * kGroupSeqs, 0);
-    for (size_t i = 0; i < lens_or_empty.size(); ++i) c->seq_len[base + i] = lens_or_empty[i];
+    for (uint64_t i = 0; i < n_lens; ++i) c->seq_len[base + i] = lens_or_null[i];
     rec.lens_known = rec.kind == 1;
     c->chunks.push_back(std::move(rec));
     c->groups_dirty = true;

@@ -61,6 +61,11 @@ void ensure_cuts(swimm_hip_ctx *c)
     }
 }
 
+// Registers a launch must leave free on every SIMD while the database is still streaming in.  The tiling kernels need 32; the
+// runtime's own copy kernels (pageable host memory travels through them) need more: with 32 free (four waves of 120) a chunk
+// copy waited 455 ms for a group-resident launch to end, with 56 free (three waves of 152) it took its 2 ms.
+static const int kUploadRoomRegs = 48;
+
 int regs_to_waves_per_simd(int regs)
 {
     const int alloc = (regs + 7) / 8 * 8;   // MI355X_MICROARCH: 8-register granule, 512 per SIMD lane
@@ -229,7 +234,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
             // registers that must stay free on every SIMD: 80 for a lane-systolic wave; 32 for the tiling waves of a database
             // that is still streaming in (c->tiling_room: a launch whose workgroups fill the register file holds the upload
             // stream's tiling kernels -- and the copies queued behind them -- back for as long as it runs)
-            const int keep = std::max(room_for_lane_waves ? 80 : 0, c->tiling_room ? 32 : 0);
+            const int keep = std::max(room_for_lane_waves ? 80 : 0, c->tiling_room ? kUploadRoomRegs : 0);
             if (keep && !c->opt_T) {
                 int regs = 0;
                 if (kernel_regs(c, mode, T, resident_for(c, passes), &regs)) return 1;
@@ -275,7 +280,7 @@ int choose_plan(swimm_hip_ctx *c, Mode mode, int m, bool room_for_lane_waves, bo
 // once).  Registers: read from the code object of the growing-list instantiation.  Cost: padded rows over the shape's measured rate.
 int choose_one_list_plan(swimm_hip_ctx *c, int m, QueryPlan *out, int *n_wg_out)
 {
-    const int kTilingRegs = 32;
+    const int kTilingRegs = kUploadRoomRegs;
     double best = -1;
     for (int ti = 7; ti >= 0; --ti) {
         const int T = 8 + 4 * ti;
@@ -336,7 +341,7 @@ int choose_batch_shapes(swimm_hip_ctx *c, Mode mode, const uint16_t *qm, uint32_
         if (c->tiling_room && !c->opt_T) {          // (a database that is still streaming in: see choose_plan)
             int regs = 0, per_cu = 1;
             if (kernel_regs(c, mode, T, true, &regs) || wgs_per_cu(c, mode, T, Wof[ti], true, &per_cu)) return 1;
-            if ((regs + 7) / 8 * 8 * ((per_cu * Wof[ti] + 3) / 4) > 512 - 32) continue;
+            if ((regs + 7) / 8 * 8 * ((per_cu * Wof[ti] + 3) / 4) > 512 - kUploadRoomRegs) continue;
         }
         ok[ti] = true;
         for (uint32_t q = 0; q < qn; ++q) cost[ti] += rows_of(qm[q], T, Wof[ti]) / rate_of(ti, Wof[ti]);

@@ -98,13 +98,13 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     g_cur_vdevice = vdevice;
     c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream_b) != hipSuccess ||
-        hipStreamCreate(&c->stream_list) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreate(&c->stream_up) != hipSuccess || hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreate(&c->stream_up) != hipSuccess || hipStreamCreate(&c->stream_list) != hipSuccess) {
         delete c;
         return fail("swimm_hip_create: stream/event creation failed");
     }

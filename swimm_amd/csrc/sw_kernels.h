@@ -131,7 +131,7 @@ struct LaneParams {
     int goe, ge;
     uint32_t *err;              // watchdog word
 };
-size_t lane_lds_bytes(Mode mode, int rows_per_lane);
+size_t lane_lds_bytes(int rows_per_lane);
 // rows_per_lane: kLaneRows (any query), or 4 / 2 for a one-pass launch of a query of <= 256 / <= 128 rows
 hipError_t launch_lane(Mode mode, int rows_per_lane, int n_wg, const LaneParams &p, hipStream_t s);
 

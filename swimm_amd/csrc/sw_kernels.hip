@@ -182,14 +182,6 @@ __device__ __forceinline__ v2h pair_score_plus(uint32_t xa, uint32_t xb, v2h hd)
     asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(xa), "v"(xb), "v"(hd));
     return t;
 }
-// a packed add whose second operand is wave-uniform and lives in a scalar register (the gap penalties in the lane-systolic
-// kernel, whose register budget is tight: a constant per VGPR less)
-__device__ __forceinline__ v2h pk_add_f16_s(v2h a, uint32_t s_bits)
-{
-    v2h d;
-    asm("v_pk_add_f16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(s_bits));
-    return d;
-}
 __device__ __forceinline__ void cell2_ofs(v2h &hd, v2h &H0, v2h &E0, v2h &H1, v2h &E1, v2h &Fp, v2h &best, uint32_t xa0, uint32_t xb0,
                                           uint32_t xa1, uint32_t xb1, v2h ngo, v2h nge, v2h fl)
 {
@@ -1057,12 +1049,7 @@ __device__ __forceinline__ uint32_t dpp_shr1(uint32_t prev, uint32_t lane0_value
 
 constexpr uint32_t kFlagStart = 1u << 16, kFlagEnd = 1u << 17, kFlagReal = 1u << 18;   // kFlagReal: a column of an item (not pipeline fill/drain)
 
-// LDS of a lane-systolic workgroup: the pass's 64 x rows-per-lane profile rows of all 25 codes; the binary16 tier holds a dword
-// (score + ge, 1.0) per row like the pipeline kernel's (pair_score_plus), the integer tiers two rows per dword
-size_t lane_lds_bytes(Mode mode, int rows_per_lane)
-{
-    return round16((size_t)kCodes * (mode == Mode::F16 ? prof_row_bytes_f16(64 * rows_per_lane) : prof_row_bytes(64 * rows_per_lane)));
-}
+size_t lane_lds_bytes(int rows_per_lane) { return round16((size_t)kCodes * prof_row_bytes(64 * rows_per_lane)); }
 
 // what lane 0 feeds into the pipeline for one chunk of 4 columns (wave-uniform)
 struct LaneFeed {
@@ -1089,8 +1076,8 @@ struct LaneFeed {
 template <int NW>
 __device__ __forceinline__ void lane_prof_load(const unsigned char *q, uint32_t (&w)[NW])
 {
-    if constexpr (NW == 4) { const uint4 v = *(const uint4 *)q; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-    else if constexpr (NW == 2) { const uint2 v = *(const uint2 *)q; w[0] = v.x; w[1] = v.y; }
+    if (NW == 4) { const uint4 v = *(const uint4 *)q; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    else if (NW == 2) { const uint2 v = *(const uint2 *)q; w[0] = v.x; w[1] = v.y; }
     else { w[0] = *(const uint32_t *)q; }
 }
 
@@ -1098,27 +1085,18 @@ __device__ __forceinline__ void lane_prof_load(const unsigned char *q, uint32_t 
 // 128 rows, whose step -- a serial walk down the lane's rows -- is then that much shorter, and with it the time a
 // 35 000-residue sequence holds up a short query.
 // M: 0 = packed int16 pairs, 1 = int32 (one sequence), 2 = packed binary16 pairs (the first tier of the long-sequence
-// tail; alignments that leave its exact range are re-run in int16 by the promotion ladder, like the pipeline kernel's).
-// The binary16 tier runs the pipeline kernel's cell update -- OFFSET form, 6.5 packed operations per row pair, the pair's score
-// formed inside the v_pk_fma_f16 that adds the diagonal (cell2_ofs above) -- with the offsets counted by STEP instead of by
-// column: at step s every lane stores its values with o_s = (s mod P) * ge added.  A lane's consecutive steps are consecutive
-// columns, so inside a lane everything is as in the pipeline kernel (E's decay is the offset's growth).  Between lanes a value
-// crosses one step: lane l - 1 computed the column at step s - 1, lane l takes it at step s.  The F it hands down, F + o_{s-1}
-// + ge, IS row 0's `a` = F + o_s -- the first subtraction of the row falls away -- and the H it hands down becomes the next
-// step's diagonal after one + ge.  Every P steps all carried state (H*, E*, the diagonal, the running best, the two values in
-// flight between lanes) is taken back by P * ge.  The running best of an ALIGNMENT (the T stream) and the boundary rows in
-// HBM stay in real space: converted where they leave / enter a lane's registers, once per item / per boundary column.
+// tail: max3 makes a row 8.5 instead of 10 packed operations and its serial F chain three instead of four long;
+// alignments that reach 2048 are re-run in int16 by the promotion ladder, like the pipeline kernel's).
 template <int M, int TR>
 __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
 {
     constexpr bool PK = M != 1;
     typedef typename std::conditional<M == 0, OpsPK, typename std::conditional<M == 1, OpsI32, OpsF16>::type>::type Ops;
     typedef typename Ops::V V;
-    constexpr bool OFS = M == 2;                                   // binary16 tier: offset form, a profile dword (score + ge, 1.0) per row
-    constexpr int C = kChunkCols, RP = 64 * TR, NW = OFS ? TR : TR / 2;   // NW dwords of profile per lane and residue
+    constexpr int C = kChunkCols, RP = 64 * TR, NW = TR / 2;   // NW dwords of profile per lane and residue
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    const int PS = OFS ? prof_row_bytes_f16(RP) : prof_row_bytes(RP);
+    const int PS = prof_row_bytes(RP);
     const uint32_t bm = p.block_map[blockIdx.x];
     const uint32_t pass = bm & 0xffu;
     const LaneQ lq = p.lq[bm >> 8];
@@ -1139,11 +1117,9 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             const int d = idx / dw_per_code, x = idx - d * dw_per_code;
             const uint32_t *src = (const uint32_t *)(p.prof + lq.prof_off + (size_t)d * lq.prof_stride + r0);
             uint32_t v = src[x];
-            if (OFS) {                              // int16 scores -> (binary16 of score + ge, 1.0) per row (pair_score_plus)
+            if (M == 2) {                           // int16 scores -> binary16
                 const v2s sv = as_v2s(v);
-                *(uint2 *)(smem + d * PS + x * 8) = make_uint2(__builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.x + p.ge), (_Float16)1.0f}),
-                                                               __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)(sv.y + p.ge), (_Float16)1.0f}));
-                continue;
+                v = __builtin_bit_cast(uint32_t, (v2h){(_Float16)(float)sv.x, (_Float16)(float)sv.y});
             }
             *(uint32_t *)(smem + d * PS + x * 4) = v;
         }
@@ -1152,19 +1128,9 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     // these waves are long serial chains (the longest alignments, or re-runs a query is waiting for) beside bulk waves
     // that step through priorities 3..0: stay near the top (priority 0 or 3 measured the same on c3)
     __builtin_amdgcn_s_setprio(2);
-    const unsigned char *my_prof = smem + lane * TR * (OFS ? 4 : 2);
+    const unsigned char *my_prof = smem + lane * TR * 2;
     const int last_lane = (int)((rows + TR - 1) / TR) - 1;      // lane holding the query's last rows in this pass
     const V goe = Ops::splat(M == 2 ? -p.goe : p.goe), ge = Ops::splat(M == 2 ? -p.ge : p.ge);
-    // offset form (binary16 tier): o_s and o_s + ge of the current step, steps since the last renormalisation, and the constants
-    // (wave-uniform: scalar operands of the packed adds -- the register budget of this kernel is 80)
-    const V ngo = Ops::splat(-(p.goe - p.ge)), pge = Ops::splat(p.ge);
-    const uint32_t renorm_steps = OFS ? (uint32_t)(kChunkCols * f16_renorm_chunks(p.ge)) : 0u;
-    const V nren = Ops::splat(-(int)renorm_steps * p.ge);
-    V off = Ops::zero(), fl = pge;                 // (fl: o_s + ge)
-    uint32_t since = 0;
-    const uint32_t s_ngo = __builtin_amdgcn_readfirstlane(Ops::bits(ngo)), s_nge = __builtin_amdgcn_readfirstlane(Ops::bits(ge));
-    const uint32_t s_pge = __builtin_amdgcn_readfirstlane(Ops::bits(pge)), s_nren = __builtin_amdgcn_readfirstlane(Ops::bits(nren));
-    auto adds = [](V x, uint32_t s_bits) -> V { if constexpr (OFS) return pk_add_f16_s(x, s_bits); else return x; };
 
     V H[TR], E[TR];
 #pragma unroll
@@ -1174,12 +1140,7 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
     // can issue the profile reads of its next column before it computes the current one.
     uint32_t oDn = 0x1818u;                  // residues this lane will hand to lane+1 (already one step ahead)
     uint32_t Dcur = 0x1818u;                 // residues + flags of the column this lane computes in this step
-    // The scores of a lane's rows for its next column are looked up one step ahead -- the first NLO dwords (one ds_read_b128 per
-    // residue); a strip of more rows than that (the binary16 tier's 8 rows = 8 dwords) fetches the rest at the top of the
-    // step that uses them: the first rows' arithmetic covers the LDS round trip, and 8 fewer registers are live.  Two buffers
-    // in alternation (the chunk loop is unrolled by an even count): no copies from "next" to "current".
-    constexpr int NLO = NW < 4 ? NW : 4, NHI = NW - NLO;
-    uint32_t abuf[2][NLO] = {}, bbuf[2][NLO] = {};
+    uint32_t acur[NW] = {}, bcur[NW] = {};
     uint32_t oH = 0, oF = 0, oT = 0, oS = 0, oC = 0;
     uint2 pb = make_uint2(0u, 0u);           // boundary-side values of the column lane 0 fed one step ago
     uint32_t pitem = 0, pcol = 0;
@@ -1285,65 +1246,22 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             if (PK) d0 |= ((cur.wb >> (8 * jj)) & 0xffu) << 8;
             // residue stream, one step ahead: fetch the scores of the NEXT column now
             const uint32_t Dn = dpp_shr1(oDn, d0);
-            static_assert(C % 2 == 0, "the lookup buffers alternate column by column");
-            uint32_t (&acur)[NLO] = abuf[jj & 1], (&bcur)[NLO] = bbuf[jj & 1];
-            uint32_t (&an)[NLO] = abuf[(jj + 1) & 1], (&bn)[NLO] = bbuf[(jj + 1) & 1];
-            lane_prof_load<NLO>(my_prof + (Dn & 0xffu) * PS, an);
-            if (PK) lane_prof_load<NLO>(my_prof + ((Dn >> 8) & 0xffu) * PS, bn);
-            uint32_t ahi[NHI ? NHI : 1] = {}, bhi[NHI ? NHI : 1] = {};      // ... and the rest of THIS column's
-            if constexpr (NHI > 0) {
-                lane_prof_load<NHI>(my_prof + (Dcur & 0xffu) * PS + NLO * 4, ahi);
-                lane_prof_load<NHI>(my_prof + ((Dcur >> 8) & 0xffu) * PS + NLO * 4, bhi);
-            }
+            uint32_t an[NW], bn[NW] = {};
+            lane_prof_load<NW>(my_prof + (Dn & 0xffu) * PS, an);
+            if (PK) lane_prof_load<NW>(my_prof + ((Dn >> 8) & 0xffu) * PS, bn);
             // boundary stream: every lane takes its left neighbour's bottom row, lane 0 the stored top boundary
             const uint32_t Hin = dpp_shr1(oH, pb.x), Fin = dpp_shr1(oF, pb.y);
             const uint32_t Tin = dpp_shr1(oT, 0u), Sin = dpp_shr1(oS, pitem), Cin = dpp_shr1(oC, pcol);
             const uint32_t D = Dcur;
             if (D & kFlagStart) {                 // first column of an alignment reaches this lane
-                if constexpr (OFS) {              // "column -1" holds H = 0 in the previous step's space; E may start below the floor (cell2_ofs)
 #pragma unroll
-                    for (int r = 0; r < TR; ++r) { H[r] = adds(off, s_nge); E[r] = Ops::zero(); }
-                    best = off; diag = H[0];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < TR; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
-                    best = Ops::zero(); diag = Ops::zero();
-                }
+                for (int r = 0; r < TR; ++r) { H[r] = Ops::zero(); E[r] = Ops::zero(); }
+                best = Ops::zero(); diag = Ops::zero();
             }
             V hd = diag;
-            const uint32_t *aw = acur;
-            V F;
-            auto xa = [&](int r) { return r < NLO ? acur[r < NLO ? r : 0] : ahi[r >= NLO ? r - NLO : 0]; };      // row r's profile dword, residue A / B
-            auto xb = [&](int r) { return r < NLO ? bcur[r < NLO ? r : 0] : bhi[r >= NLO ? r - NLO : 0]; };
-            if constexpr (OFS) {
-                // the row above was computed one step ago: its H + o_{s-1} becomes the next step's diagonal after + ge, and its
-                // F' = F + o_{s-1} + ge is F + o_s already -- row 0's `a`
-                diag = adds(Ops::from_bits(Hin), s_pge);
-                V a = Ops::from_bits(Fin);
-#pragma unroll
-                for (int r = 0; r < TR; r += 2) {
-                    const V t0 = pair_score_plus(xa(r), xb(r), hd);
-                    hd = H[r];
-                    const V h0 = OpsF16::max3(t0, E[r], a);
-                    H[r] = h0;
-                    const V u0 = pk_add_f16_s(h0, s_ngo);
-                    E[r] = pk_max_f16(E[r], u0);
-                    F = OpsF16::max3(a, u0, fl);
-                    a = pk_add_f16_s(F, s_nge);
-                    const V t1 = pair_score_plus(xa(r + 1), xb(r + 1), hd);
-                    hd = H[r + 1];
-                    const V h1 = OpsF16::max3(t1, E[r + 1], a);
-                    H[r + 1] = h1;
-                    const V u1 = pk_add_f16_s(h1, s_ngo);
-                    E[r + 1] = pk_max_f16(E[r + 1], u1);
-                    F = OpsF16::max3(a, u1, fl);
-                    if (r + 2 < TR) a = pk_add_f16_s(F, s_nge);
-                    best = OpsF16::max3(best, h0, h1);
-                    asm("" : "+v"(best));
-                }
-            } else {
             diag = Ops::from_bits(Hin);
-            F = Ops::from_bits(Fin);
+            V F = Ops::from_bits(Fin);
+            const uint32_t *aw = acur;
             if constexpr (PK) {
                 const uint32_t *bw = bcur;
 #pragma unroll
@@ -1357,18 +1275,11 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
                     cell<Ops>(hd, H[2 * q + 1], E[2 * q + 1], F, best, Ops::from_bits((uint32_t)((int)aw[q] >> 16)), goe, ge);
                 }
             }
-            }
             oH = Ops::bits(H[TR - 1]); oF = Ops::bits(F); oS = Sin; oC = Cin; oT = Tin;
-            if (D & kFlagEnd) {                   // running best of the alignment (the T stream is in real space)
-                if constexpr (OFS) oT = Ops::bits(Ops::vmax(Ops::from_bits(Tin), best - off));
-                else oT = Ops::bits(Ops::vmax(Ops::from_bits(Tin), best));
-            }
+            if (D & kFlagEnd) oT = Ops::bits(Ops::vmax(Ops::from_bits(Tin), best));   // running best of the alignment
             const bool mine = lane == last_lane && (D & kFlagReal);   // fill / drain columns must never reach real memory
-            if (!last_pass && mine) {   // one lane, four stores per real chunk (lane 63's chunks are chunk aligned); real space in HBM
-                uint32_t sH = oH, sF = oF;
-                if constexpr (OFS) { sH = Ops::bits(H[TR - 1] - off); sF = Ops::bits(F - fl); }
-                __hip_atomic_store(bnd_out + Cin, ((unsigned long long)sF << 32) | sH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (!last_pass && mine)   // one lane, four stores per real chunk (lane 63's chunks are chunk aligned)
+                __hip_atomic_store(bnd_out + Cin, ((unsigned long long)oF << 32) | oH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine && (D & kFlagEnd)) {   // every pass contributes the best of its own rows
                 const LaneItem *iv = items + Sin;
                 if (M == 2) {
@@ -1385,23 +1296,9 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
             }
             // advance both streams
             oDn = Dn; Dcur = Dn;
-            pb = cur.b[jj]; pitem = cur.item; pcol = cur.col0 + jj;
-            if constexpr (OFS) {
-                // what lane 0 takes next step must look like a lane's hand-over of THIS step: H + o_s, F + o_s + ge (the stored
-                // boundary rows are in real space; the first pass has none: H = F = 0)
-                pb = first_pass ? make_uint2(Ops::bits(off), Ops::bits(fl))
-                                : make_uint2(Ops::bits(Ops::from_bits(pb.x) + off), Ops::bits(Ops::from_bits(pb.y) + fl));
-                best = adds(best, s_pge);                    // the running best, in the next step's space
-                off = fl; fl = adds(fl, s_pge);              // o_{s+1}
-                if (++since == renorm_steps) {               // the offsets have grown for P steps: take every carried value back by P * ge
 #pragma unroll
-                    for (int r = 0; r < TR; ++r) { H[r] = adds(H[r], s_nren); E[r] = adds(E[r], s_nren); }
-                    diag = adds(diag, s_nren); best = adds(best, s_nren);
-                    oH = Ops::bits(adds(Ops::from_bits(oH), s_nren)); oF = Ops::bits(adds(Ops::from_bits(oF), s_nren));
-                    pb = make_uint2(Ops::bits(adds(Ops::from_bits(pb.x), s_nren)), Ops::bits(adds(Ops::from_bits(pb.y), s_nren)));
-                    off = Ops::zero(); fl = Ops::from_bits(s_pge); since = 0;
-                }
-            }
+            for (int q = 0; q < NW; ++q) { acur[q] = an[q]; bcur[q] = bn[q]; }
+            pb = cur.b[jj]; pitem = cur.item; pcol = cur.col0 + jj;
         }
         if (!last_pass && ((hist_real >> 16) & 1u)) {
             // Lane 63 has just stored the boundary of the chunk fed 16 iterations ago, which ends at column oC of item
@@ -1415,7 +1312,7 @@ __global__ void __launch_bounds__(256, 6) sw_lane_kernel(const LaneParams p)
 template <int TR>
 static hipError_t launch_lane_tr(Mode mode, int n_wg, const LaneParams &p, hipStream_t s)
 {
-    const size_t lds = lane_lds_bytes(mode, TR);
+    const size_t lds = lane_lds_bytes(TR);
     if (mode == Mode::PK16) hipLaunchKernelGGL((sw_lane_kernel<0, TR>), dim3(n_wg), dim3(256), lds, s, p);
     else if (mode == Mode::F16) hipLaunchKernelGGL((sw_lane_kernel<2, TR>), dim3(n_wg), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((sw_lane_kernel<1, TR>), dim3(n_wg), dim3(256), lds, s, p);

@@ -1,3 +1,4 @@
-mkdir -p gpurun_out/r4_g21
-EXP_DEBUG=1 timeout -k 10 300 python tools/exp_ctx.py 2>&1 | grep -v "query [0-9]* m=\|range [0-9]*: T=\|host time of a timed\|pipeline launch\|plan candidate\|bulk on\|workgroups, " > gpurun_out/r4_g21/ctx.txt
+mkdir -p gpurun_out/r4_g23
+for sc in 0.1 0.3 1.0; do timeout -k 10 100 python tools/bench_configs.py --config c3 --scale $sc --reps 3 >> gpurun_out/r4_g23/c3_scales.txt 2>&1; done
+timeout -k 10 700 python -m pytest tests -x -q -m gpu -k "c3 or edges or fuzz or golden or lane or tail" > gpurun_out/r4_g23/tests.txt 2>&1
 echo done

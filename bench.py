@@ -481,10 +481,10 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
         ok, stride, n_s, res_s, cpu_s, kind, chk_in = sample_check(w["qa_list"], w["my_lens"], w["codes_of"], sm, chk_threads, lambda idx: mine_scores[:, idx], cpu_budget, my_n)
         m0_gcups = None
         if world == 1 and want_cpu_baseline:
-            # the product's own -m 0 on a slice of the same sample (it is several times slower than the reference's AVX2 path:
-            # a tenth of the sample keeps it within seconds), same threads
+            # the product's own -m 0 on the same sample when the checker took under 2 s on it, else on every third block of it
+            # (keeps the default run within minutes), same threads
             o = np.concatenate([[0], np.cumsum(chk_in[0].astype(np.int64))])
-            blocks = range(0, len(chk_in[0]), SAMPLE_BLOCK * 10)
+            blocks = range(0, len(chk_in[0]), SAMPLE_BLOCK * (1 if cpu_s < 2.0 else 3))
             sub_l = np.concatenate([chk_in[0][b:b + SAMPLE_BLOCK] for b in blocks])
             sub_c = np.concatenate([chk_in[1][o[b]:o[min(b + SAMPLE_BLOCK, len(chk_in[0]))]] for b in blocks])
             m0_gcups = product_m0_gcups(w["qa_list"], sub_l, sub_c, sm, chk_threads)
@@ -643,7 +643,7 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
                                    "sample": (f"{name} shard, " + ("every sequence" if stride == 1 else f"every {stride}th block of {SAMPLE_BLOCK} consecutive sequences") +
                                               f" ({n_s} sequences, {res_s} residues), {nq} quer{'y' if nq == 1 else 'ies'}, {cpu_s:.2f} s"),
                                    "product_m0": round(m0_gcups, 2) if m0_gcups else None,
-                                   "product_m0_note": (f"the product's own -m 0 (swimm_cpu_search: int32 lanes, auto-vectorised) on {m0_sample[0]} sequences / {m0_sample[1]} residues of the same sample, "
+                                   "product_m0_note": (f"the product's own -m 0 (swimm_cpu_search: AVX2 int8 -> int16 -> int32 tiers, one sequence per lane, column-major sweep) on {m0_sample[0]} sequences / {m0_sample[1]} residues of the same sample, "
                                                        f"{chk_threads} threads: the host leg of `swimm -m 2` and all of BASELINE config 1; the reference's AVX2 path beside it is `value`")}
     searcher.close()
     if w["chunks"] is not None:

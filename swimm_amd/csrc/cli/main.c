@@ -438,10 +438,12 @@ int main(int argc, char **argv)
 
     /* mode 0 pads odd queries to even length (sequences.c:378-387); the accelerator mode does not (347-364) */
     swimm_queries q;
+    const double t_load0 = swimm_wtime();
     int rc = swimm_queries_load(o.queries_filename, gpu_mode ? 0 : 1, &q);
     if (rc) die_host(rc);
     swimm_db db;
     if ((rc = swimm_db_load(o.db_prefix, &db))) die_host(rc);
+    const double t_load = swimm_wtime() - t_load0;
     unsigned long top = db.count < o.top ? db.count : o.top;   /* swimm.c:51 */
 
     printf("Database size:\t\t\t%ld sequences (%ld residues) \n", (long)db.count, (long)db.residues);
@@ -504,7 +506,11 @@ int main(int argc, char **argv)
 
     /* titles of the reported hits only (the reference loads all N, sequences.c:757-761) */
     char **titles = (char **)malloc(q.count * top * sizeof(char *));
+    const double t_titles0 = swimm_wtime();
     if ((rc = swimm_db_titles(o.db_prefix, db.count, top_idx, q.count * top, titles))) die_host(rc);
+    if (getenv("SWIMM_DEBUG"))          /* the wall-clock split of a search, for tools/cli_scale.py */
+        fprintf(stderr, "swimm: load %.4f s, search %.4f s, titles %.4f s (%lu titles)\n", t_load, workTime, swimm_wtime() - t_titles0,
+                (unsigned long)(q.count * top));
     for (uint64_t i = 0; i < q.count; ++i) {
         printf("\nQuery no.\t\t\t%d\n", (int)i + 1);
         printf("Query description: \t\t%s\n", q.titles[i] + 1);
@@ -519,7 +525,7 @@ int main(int argc, char **argv)
     if (o.execution_mode == MODE_CPU_ONLY) {
         printf("Execution mode:\t\t\tHost CPU only (%d threads, block width = %d)\n", o.cpu_threads, o.cpu_block_size);
         printf("Profile technique:\t\tSubstitution row per query residue\n");
-        printf("Instruction set:\t\tcompiler-vectorised int32 lanes (vector length = %d)\n", o.vector_length);
+        printf("Instruction set:\t\tAVX2 int8 -> int16 -> int32 ladder, one sequence per lane (vector length = %d)\n", o.vector_length);
     } else {
         if (o.execution_mode == MODE_HYBRID)
             printf("Execution mode:\t\t\tConcurrent host CPU and MI355X (%d CPU threads and %d GPUs)\n", o.cpu_threads, o.num_gpus);

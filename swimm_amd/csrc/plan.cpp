@@ -121,8 +121,10 @@ int list_copy(swimm_hip_ctx *c, void *dst, const void *src, size_t bytes)
     c->pin_used += (bytes + 255) & ~(size_t)255;
     return 0;
 }
+double g_list_sync_wait_s = 0;          // (debug aid: seconds the host spent in list_sync since it was last zeroed)
 int list_sync(swimm_hip_ctx *c)
 {
+    struct Tm { double t0; Tm() : t0(now_s()) {} ~Tm() { g_list_sync_wait_s += now_s() - t0; } } tm;
     HIP_TRY(hipStreamSynchronize(list_stream(c)));
     c->pin_used = 0;
     return 0;

@@ -557,7 +557,8 @@ int SearchRun::layout_ranges()
         for (const ChunkRec &r : c->chunks) {
             if (r.uploaded) continue;
             mb = std::max<uint64_t>(mb, r.kind == 0 ? r.vD : r.code_bytes); mn = std::max<uint64_t>(mn, r.group_count);
-            mg = std::max<uint64_t>(mg, r.n_groups); mo = std::max<uint64_t>(mo, r.off.size());
+            mg = std::max<uint64_t>(mg, r.n_groups); mo = std::max<uint64_t>(mo, r.gsrc.size());
+            if (r.kind == 1) mn = std::max<uint64_t>(mn, r.n_seq);
         }
         // the upload scratch grows now, not between two chunks (growing frees the old buffer)
         HIP_TRY(c->up_b.reserve(mb)); HIP_TRY(c->up_n.reserve(mn)); HIP_TRY(c->up_disp.reserve(mn));
@@ -683,7 +684,8 @@ int SearchRun::layout_ranges()
     const size_t np = up_order.size();
     if (ensure_uploader(c)) return 1;
     c->up->post(up_order);
-    if (dbg) fprintf(stderr, "swimm_hip: upload order laid out (%zu parts%s), uploader started %.3f ms after the call began\n", np, one_list ? ", one item list" : "", (now_s() - t_begin) * 1e3);
+    if (dbg) fprintf(stderr, "swimm_hip: upload order laid out (%zu parts%s), uploader started %.3f ms after the call began; the add calls before it took %.3f ms\n", np, one_list ? ", one item list" : "", (now_s() - t_begin) * 1e3, c->add_seconds * 1e3);
+    c->add_seconds = 0;
     if (one_list) {
         ranges.push_back(whole_range(c));
         range_chunks.push_back({0, np});
@@ -702,6 +704,31 @@ int SearchRun::layout_ranges()
     for (size_t i = 0; i < np; ++i) pcols[i] = part_cols(up_order[i]);
     auto up_s = [&](size_t i) { return (double)pcols[i] * kGroupSeqs / 40e9; };
     auto dp_s = [&](size_t i) { return 0.85 * rows * (double)pcols[i] * kGroupSeqs / 8000e9; };   // (rather too short: the GPU must not wait)
+    // ... and no larger than it must be: the ranges that run while the database lands take launch shapes that leave the tiling
+    // waves their registers (plan_queries), and the last range -- everything that is left once the GPU has work until the link has
+    // delivered the last byte -- runs like a resident database.  So a range closes as soon as the ranges so far keep the GPU busy
+    // for 1.1 of the whole upload, and what follows is the last range: a 5 478-row query needs 4 % of a 7e9-residue database before
+    // the other 96 % are there (first built without this rule: a third of the database in a register-lean early range, +4.9 %).
+    double up_total = 0, dp_total = 0;
+    for (size_t i = 0; i < np; ++i) { up_total += up_s(i); dp_total += dp_s(i); }
+    // A database that lands in under 1.5 % of the time its alignment takes is not streamed at all: the search waits for the
+    // uploader and runs as on a resident database -- the same launches, work lists and streams (c3's 20 queries: 5 ms of upload
+    // before 840 ms of kernels; as two ranges the first -- an eighth of the database in 108 small launches of register-lean
+    // shapes -- cost 6 %; c5: 40 ms before 7.2 s).
+    if (up_total <= 0.015 * dp_total) {
+        if (dbg) fprintf(stderr, "swimm_hip: the database lands in %.1f ms, its alignment takes %.0f ms: waiting for it, then searching it as a resident one\n", up_total * 1e3, dp_total * 1e3);
+        if (wait_uploaded(np)) return 1;
+        const UploadPart &last = up_order[np - 1];              // (the upload stream is in order)
+        for (hipStream_t st : {c->stream, c->stream_b, c->stream2, c->stream3}) HIP_TRY(hipStreamWaitEvent(st, last.ready, 0));
+        if (dbg) fprintf(stderr, "swimm_hip: host copies done %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
+        c->up->finish(false);
+        streaming = false;
+        c->streaming_now = false;
+        c->stream_tail.clear();
+        if (sync_lengths(c)) return 1;
+        ranges.push_back(whole_range(c));
+        return 0;
+    }
     double t_up = 0, t_gpu = 0;
     for (size_t i = 0; i < np;) {
         Range rg; rg.g0 = c->chunks[up_order[i].chunk].group0 + up_order[i].g0; rg.g1 = c->chunks[up_order[i].chunk].group0 + up_order[i].g1; rg.cols = 0;
@@ -717,7 +744,7 @@ int SearchRun::layout_ranges()
                 const uint32_t n0 = c->chunks[up_order[i].chunk].group0 + up_order[i].g0, n1 = c->chunks[up_order[i].chunk].group0 + up_order[i].g1;
                 if (n0 != rg.g1 && n1 != rg.g0) break;
             }
-        } while (i < np && t_up + up_s(i) <= t_gpu);
+        } while (i < np && t_up + up_s(i) <= t_gpu && (t_gpu >= 1.1 * up_total || std::max(t_gpu, t_up) + work < 1.1 * up_total));
         t_gpu = std::max(t_gpu, t_up) + work;
         ranges.push_back(rg);
         range_chunks.push_back({first, i});
@@ -755,7 +782,8 @@ int SearchRun::plan_queries()
     // query's end are zero, like the reference's dummy row 23
     range_pp.assign(ranges.size(), 0);
     alternate_pp = false;
-    c->tiling_room = streaming;            // launch shapes of a database that is still landing leave the tiling waves their registers
+    const bool landing = streaming;
+    c->tiling_room = landing;              // launch shapes of a database that is still landing leave the tiling waves their registers
     if (one_list) {          // one query, one pass, one launch over the whole database as it lands (layout_ranges)
         qps.assign(1, one_list_qp);
         rotated.assign(1, 0); use_sp.assign(1, 0); in_batch.assign(1, 0); stack_of.assign(1, -1);
@@ -926,7 +954,7 @@ int SearchRun::plan_queries()
                 if (use_sp[q]) { rqps[ri][q] = qps[q]; continue; }
                 c->tiling_room = streaming && ri + 1 < ranges.size();       // (the last range's launches start when everything has landed)
                 const int rc_plan = choose_plan(c, main_mode, qm[q], room, false, &rqps[ri][q], &ranges[ri], &rbulk[ri]);
-                c->tiling_room = streaming;
+                c->tiling_room = landing;
                 if (rc_plan) return 1;
                 qps[q].mpad = std::max(qps[q].mpad, rqps[ri][q].mpad);
                 if (dbg) fprintf(stderr, "swimm_hip:   range %zu: T=%d W=%d passes=%d\n", ri, rqps[ri][q].T, rqps[ri][q].W, rqps[ri][q].passes);
@@ -1359,9 +1387,11 @@ int SearchRun::issue()
         // the next range's work lists need its geometry only: build them now, while the GPU aligns this range and
         // before the host blocks in the next range's copies
         if (dbg && streaming) fprintf(stderr, "swimm_hip: range %zu: launches issued %.3f ms after the call began\n", ri, (now_s() - t_begin) * 1e3);
+        extern double g_list_sync_wait_s;
+        g_list_sync_wait_s = 0;
         if (streaming && ri + 1 < ranges.size())
             for (uint32_t q = 0; q < qn; ++q) { DbPlan *dp = nullptr; if (plan_of(ri + 1, q, &dp)) return 1; }
-        if (dbg && streaming) fprintf(stderr, "swimm_hip: range %zu: next range's work lists built %.3f ms after the call began\n", ri, (now_s() - t_begin) * 1e3);
+        if (dbg && streaming) fprintf(stderr, "swimm_hip: range %zu: next range's work lists built %.3f ms after the call began (%.3f ms of it waiting for the lists' copies)\n", ri, (now_s() - t_begin) * 1e3, g_list_sync_wait_s * 1e3);
     }
     if (streaming) {
         // the ranges took turns on the bulk streams (and the tail stream, for group-resident launches): "query q's bulk

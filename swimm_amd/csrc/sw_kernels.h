@@ -169,9 +169,10 @@ hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *di
                          const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint32_t max_cols /* longest group */, uint8_t *tiled,
                          uint32_t *seq_len /* [dev_groups*128], zeroed; gets every sequence's true length */, hipStream_t s);
 
-// Tile a slab of sorted sequences (concatenated codes + offsets, as in the .seq file) into device groups directly.
-hipError_t launch_tile_sequences(const uint8_t *codes, const uint32_t *seq_off /* [n_seq + 1] */, uint32_t n_seq, const uint64_t *goff,
-                                 const uint32_t *gcols, uint32_t dev_groups, uint32_t max_cols /* longest group */, uint8_t *tiled, hipStream_t s);
+// Tile a slab of sorted sequences (lengths + concatenated codes, as in the .seq file) into device groups directly.
+hipError_t launch_tile_sequences(const uint8_t *codes, const uint16_t *lens /* [n_seq] */, const uint32_t *gsrc /* [dev_groups]: offset of every group's first residue in codes */,
+                                 uint32_t n_seq, const uint64_t *goff, const uint32_t *gcols, uint32_t dev_groups, uint32_t max_cols /* longest group */, uint8_t *tiled,
+                                 hipStream_t s);
 
 // appends the slots whose score is >= thr (tier left its exact range) to list (up to cap) and zeroes them
 // items of a streaming search's list that are on the device (PipeParams::avail); kAvailAbort = the upload failed: give up

@@ -1402,20 +1402,39 @@ hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *di
 // are and the device builds its own layout, instead of the host interleaving lanes first (sequences.c:506-526)
 // and retile_kernel undoing it.  Group g holds sequences 128 g .. 128 g + 127 of the slab; lane l of chunk c gets
 // columns 4c..4c+3 of sequence 2l (low dword) and of sequence 2l + 1 (high dword), code 24 past a sequence's end.
-__global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const uint32_t *__restrict__ seq_off, uint32_t n_seq,
-                                      const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols,
+__global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const uint16_t *__restrict__ lens, const uint32_t *__restrict__ gsrc,
+                                      uint32_t n_seq, const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols,
                                       uint8_t *__restrict__ tiled)
 {
     __builtin_amdgcn_s_setprio(3);                    // (see retile_kernel)
     const uint32_t g = blockIdx.x;
     const uint32_t nch = gcols[g] / kChunkCols;
+    // where the group's 128 sequences begin: the host hands over the lengths as the .seq file holds them and ONE offset per
+    // group; the offsets within the group are a scan over 128 lengths here (the host's walk over 35 M sequences stays two
+    // reductions per group -- swimm_hip_add_sequences)
+    __shared__ uint32_t s_len[kGroupSeqs], s_beg[kGroupSeqs];
+    if (threadIdx.x < kGroupSeqs) {
+        const uint32_t sq = g * kGroupSeqs + threadIdx.x;
+        const uint32_t l = sq < n_seq ? lens[sq] : 0u;
+        s_len[threadIdx.x] = l;
+        s_beg[threadIdx.x] = l;
+    }
+    __syncthreads();
+    for (uint32_t d = 1; d < kGroupSeqs; d <<= 1) {          // inclusive scan, 7 steps
+        uint32_t add = 0;
+        if (threadIdx.x < kGroupSeqs && threadIdx.x >= d) add = s_beg[threadIdx.x - d];
+        __syncthreads();
+        if (threadIdx.x < kGroupSeqs) s_beg[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const uint32_t base = gsrc[g];
     for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nch * 128; idx += gridDim.y * blockDim.x) {
-        const uint32_t c = idx >> 7;
-        const uint32_t s = g * kGroupSeqs + (idx & 127);          // (one (chunk, sequence) dword per thread and iteration: see retile_kernel)
+        const uint32_t c = idx >> 7, sl = idx & 127;            // (one (chunk, sequence) dword per thread and iteration: see retile_kernel)
         uint32_t word = 0x18181818u;              // four padding codes (24)
-        if (s < n_seq) {
-            const uint32_t b0 = seq_off[s], len = seq_off[s + 1] - b0;
-            const uint32_t col = c * kChunkCols;
+        const uint32_t len = s_len[sl];
+        const uint32_t col = c * kChunkCols;
+        if (col < len) {
+            const uint32_t b0 = base + s_beg[sl] - len;      // (exclusive = inclusive - own)
             if (col + kChunkCols <= len) {
                 // four residues inside the sequence: one (unaligned) dword, codes above 24 clamped to the padding code
                 uint32_t x;
@@ -1438,11 +1457,11 @@ __global__ void tile_sequences_kernel(const uint8_t *__restrict__ codes, const u
     }
 }
 
-hipError_t launch_tile_sequences(const uint8_t *codes, const uint32_t *seq_off, uint32_t n_seq, const uint64_t *goff,
+hipError_t launch_tile_sequences(const uint8_t *codes, const uint16_t *lens, const uint32_t *gsrc, uint32_t n_seq, const uint64_t *goff,
                                  const uint32_t *gcols, uint32_t dev_groups, uint32_t max_cols, uint8_t *tiled, hipStream_t s)
 {
     if (dev_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_sequences_kernel, dim3(dev_groups, tile_slices(max_cols)), dim3(256), 0, s, codes, seq_off, n_seq, goff, gcols, tiled);
+    hipLaunchKernelGGL(tile_sequences_kernel, dim3(dev_groups, tile_slices(max_cols)), dim3(256), 0, s, codes, lens, gsrc, n_seq, goff, gcols, tiled);
     return hipGetLastError();
 }
 

@@ -78,6 +78,32 @@ int swimm_hip_bind_host_thread(int device, int num_devices, char *cpulist_out, s
     return 0;
 }
 
+// The context's streams and the hardware queues behind them.  The runtime multiplexes the streams of one priority class onto a
+// pool of four hardware queues (first use takes a queue of its own while the pool is not full, then the least-used one), and a
+// packet waits for everything in front of it in ITS hardware queue: a work-list copy on a stream that shared a queue with a
+// group-resident range launch waited 60-400 ms for that launch to end (r04, c4 / c5 cold; profiles/NOTES.md).  So
+//   - the work-list stream is of the HIGH priority class: a pool of its own, never behind a launch stream;
+//   - the upload stream stays in the normal class (in a class of its own every copy -> tile -> publish step of the one-launch
+//     search cost more: c2 cold 27.5 -> 28.7 ms) but is the FIRST stream of the context to be used, then the three launch
+//     streams: each of the four takes a queue of its own where the process holds no other stream, and when it does (torch's null
+//     stream in bench.py) the one that has to share is the ladder stream, which runs when the uploads are over.
+static hipError_t make_streams(swimm_hip_ctx *c)
+{
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamCreate(&c->stream_up)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream_b)) != hipSuccess ||
+        (e = hipStreamCreate(&c->stream2)) != hipSuccess || (e = hipStreamCreate(&c->stream3)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&c->stream_list, hipStreamDefault, hi)) != hipSuccess) return e;
+    void *tmp = nullptr;
+    if ((e = hipMalloc(&tmp, 256)) != hipSuccess) return e;
+    for (hipStream_t st : {c->stream_up, c->stream, c->stream_b, c->stream2, c->stream3, c->stream_list}) {      // first use, in this order
+        if ((e = hipMemsetAsync(tmp, 0, 64, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) break;
+    }
+    (void)hipFree(tmp);
+    return e;
+}
+
 int swimm_hip_create(int device, swimm_hip_ctx **out)
 {
     if (!out) return fail("swimm_hip_create: out is NULL");
@@ -97,14 +123,13 @@ int swimm_hip_create(int device, swimm_hip_ctx **out)
     c->vdevice = vdevice;
     g_cur_vdevice = vdevice;
     c->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream_b) != hipSuccess ||
+    if (make_streams(c) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreate(&c->stream3) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_tail3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreate(&c->stream_up) != hipSuccess || hipStreamCreate(&c->stream_list) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return fail("swimm_hip_create: stream/event creation failed");
     }
@@ -253,65 +278,89 @@ int swimm_hip_add_chunk(swimm_hip_ctx *c, const char *b, uint64_t vD, const uint
     return 0;
 }
 
-static int add_sequences_piece(swimm_hip_ctx *c, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq);
+// One walk over a slab's lengths, and a light one: per device group of 128 sequences the residues it holds and its longest
+// member (two reductions over 128 uint16 the compiler vectorises; no per-sequence offsets -- the tiling kernel makes its own from
+// the lengths -- and no second array of the slab's size: this runs inside the caller's "first search after a cold upload", 35 M
+// sequences at the full Env-NR size, where round 4's first version -- offsets of every sequence, lengths widened to 32 bits -- took
+// 33 ms, most of it first touches of 280 MB of fresh memory).
+static void group_sums(const uint16_t *lengths, uint64_t n_seq, std::vector<uint32_t> &gsum, std::vector<uint32_t> &gmax)
+{
+    const uint64_t ng = (n_seq + kGroupSeqs - 1) / kGroupSeqs;
+    gsum.resize(ng); gmax.resize(ng);
+    for (uint64_t g = 0; g < ng; ++g) {
+        const uint16_t *l = lengths + g * kGroupSeqs;
+        const uint32_t n = (uint32_t)std::min<uint64_t>(kGroupSeqs, n_seq - g * kGroupSeqs);
+        uint32_t sum = 0;
+        uint16_t mx = 1;
+        for (uint32_t i = 0; i < n; ++i) { sum += l[i]; mx = std::max(mx, l[i]); }
+        gsum[g] = sum; gmax[g] = mx;
+    }
+}
+
+static int add_sequences_piece(swimm_hip_ctx *c, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq, const uint32_t *gsum,
+                               const uint32_t *gmax, uint8_t *tiled = nullptr, size_t tiled_cap = 0)
+{
+    ChunkRec rec;
+    rec.kind = 1;
+    rec.d_tiled = tiled; rec.tiled_cap = tiled_cap;      // (a piece of a slab: its share of the slab's one device buffer)
+    rec.n_groups = (uint32_t)((n_seq + kGroupSeqs - 1) / kGroupSeqs);
+    rec.goff.resize(rec.n_groups);
+    rec.gcols.resize(rec.n_groups);
+    rec.gsrc.resize((size_t)rec.n_groups + 1);
+    uint64_t total = 0;
+    for (uint32_t g = 0; g < rec.n_groups; ++g) {
+        rec.gsrc[g] = (uint32_t)total;
+        total += gsum[g];
+        if (total > 0xFFFFFFF0ull) return fail("swimm_hip_add_sequences: slab larger than 4 GiB");
+        rec.gcols[g] = (gmax[g] + kChunkCols - 1) / kChunkCols * kChunkCols;
+    }
+    rec.gsrc[rec.n_groups] = (uint32_t)total;
+    if (ctx_enter(c)) return 1;
+    rec.h_codes = codes; rec.code_bytes = total;
+    rec.h_len = lengths;
+    rec.first_seq = first_seq;
+    rec.n_seq = n_seq;
+    if (register_chunk(c, rec, lengths, n_seq)) return 1;
+    if (c->opt_lazy_upload ? ensure_uploader(c) : upload_chunk(c, c->chunks.back())) return 1;
+    return 0;
+}
 
 int swimm_hip_add_sequences(swimm_hip_ctx *c, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq)
 {
     if (!c || !lengths || !codes) return fail("swimm_hip_add_sequences: NULL argument");
     if (n_seq == 0) return fail("swimm_hip_add_sequences: empty slab");
     if (n_seq > 0x7FFFFFFFull) return fail("swimm_hip_add_sequences: more than 2^31 sequences in one slab");
-    if (!c->opt_lazy_upload) return add_sequences_piece(c, lengths, codes, n_seq, first_seq);
+    struct Tm { swimm_hip_ctx *c; double t0; ~Tm() { c->add_seconds += now_s() - t0; } } tm{c, now_s()};
+    std::vector<uint32_t> gsum, gmax;
+    group_sums(lengths, n_seq, gsum, gmax);
+    if (!c->opt_lazy_upload) return add_sequences_piece(c, lengths, codes, n_seq, first_seq, gsum.data(), gmax.data());
     // (lazy_upload: pieces of about upload_piece_kib, whole device groups each -- see swimm_hip_add_chunk)
+    // ONE device buffer for the slab, shared by its pieces (the first piece owns it): a cold search of a 7e9-residue database is
+    // 8 allocations instead of 74 -- and the same 8 sizes as an eager upload of the same slabs, so that a database that replaces
+    // another finds its buffers in the pool (the 74 pieces of c4 did not: up to 1 s of hipMalloc / hipFree inside the first search)
     const uint64_t piece = (uint64_t)c->opt_upload_piece_kib << 10;
-    uint64_t off = 0;
-    for (uint64_t s0 = 0; s0 < n_seq;) {
-        uint64_t s1 = s0, bytes = 0;
-        do {
-            const uint64_t e = std::min<uint64_t>(n_seq, s1 + kGroupSeqs);
-            for (uint64_t i = s1; i < e; ++i) bytes += lengths[i];
-            s1 = e;
-        } while (s1 < n_seq && bytes < piece);
-        if (n_seq - s1 < (uint64_t)kGroupSeqs * 4 && bytes < piece + piece / 2) {          // (no sliver at the end)
-            for (uint64_t i = s1; i < n_seq; ++i) bytes += lengths[i];
-            s1 = n_seq;
-        }
-        if (add_sequences_piece(c, lengths + s0, codes + off, s1 - s0, first_seq + s0)) return 1;
-        off += bytes;
-        s0 = s1;
-    }
-    return 0;
-}
-
-static int add_sequences_piece(swimm_hip_ctx *c, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq)
-{
-    // (one walk over the lengths: residue offsets, every device group's longest member -- this runs inside the caller's
-    // "first search after a cold upload", 35 M sequences at the full Env-NR size)
-    ChunkRec rec;
-    rec.kind = 1;
-    rec.off.resize(n_seq + 1);
-    rec.n_groups = (uint32_t)((n_seq + kGroupSeqs - 1) / kGroupSeqs);
-    rec.goff.resize(rec.n_groups);
-    rec.gcols.resize(rec.n_groups);
-    uint64_t total = 0;
-    uint32_t *off = rec.off.data();
-    for (uint32_t g = 0; g < rec.n_groups; ++g) {
-        uint32_t mx = 1;
-        const uint64_t e = std::min<uint64_t>(n_seq, (uint64_t)(g + 1) * kGroupSeqs);
-        for (uint64_t i = (uint64_t)g * kGroupSeqs; i < e; ++i) {
-            off[i] = (uint32_t)total;
-            total += lengths[i];
-            mx = std::max<uint32_t>(mx, lengths[i]);
-        }
-        if (total > 0xFFFFFFF0ull) return fail("swimm_hip_add_sequences: slab larger than 4 GiB");
-        rec.gcols[g] = (mx + kChunkCols - 1) / kChunkCols * kChunkCols;
-    }
-    off[n_seq] = (uint32_t)total;
+    const uint64_t ng = gsum.size();
+    uint64_t tiled_total = 0;
+    for (uint64_t g = 0; g < ng; ++g) tiled_total += (uint64_t)((gmax[g] + kChunkCols - 1) / kChunkCols * kChunkCols) * kGroupSeqs;
     if (ctx_enter(c)) return 1;
-    rec.h_codes = codes; rec.code_bytes = total;
-    rec.first_seq = first_seq;
-    rec.n_seq = n_seq;
-    if (register_chunk(c, rec, lengths, n_seq)) return 1;
-    if (c->opt_lazy_upload ? ensure_uploader(c) : upload_chunk(c, c->chunks.back())) return 1;
+    uint8_t *slab = nullptr;
+    size_t slab_cap = 0;
+    if (pool_alloc(c, std::max<uint64_t>(tiled_total, 16), (void **)&slab, &slab_cap)) return 1;
+    uint64_t off = 0, tiled_off = 0;
+    for (uint64_t g0 = 0; g0 < ng;) {
+        uint64_t g1 = g0, bytes = 0;
+        do { bytes += gsum[g1]; ++g1; } while (g1 < ng && bytes < piece);
+        if (ng - g1 < 4 && bytes < piece + piece / 2)          // (no sliver at the end)
+            for (; g1 < ng; ++g1) bytes += gsum[g1];
+        const uint64_t s0 = g0 * kGroupSeqs, s1 = std::min<uint64_t>(n_seq, g1 * kGroupSeqs);
+        if (add_sequences_piece(c, lengths + s0, codes + off, s1 - s0, first_seq + s0, gsum.data() + g0, gmax.data() + g0, slab + tiled_off, g0 == 0 ? slab_cap : 0)) {
+            if (g0 == 0) (void)hipFree(slab);          // (nobody owns it yet)
+            return 1;
+        }
+        for (uint64_t g = g0; g < g1; ++g) tiled_off += (uint64_t)((gmax[g] + kChunkCols - 1) / kChunkCols * kChunkCols) * kGroupSeqs;
+        off += bytes;
+        g0 = g1;
+    }
     return 0;
 }
 
@@ -322,7 +371,7 @@ int swimm_hip_clear_db(swimm_hip_ctx *c)
     (void)hipDeviceSynchronize();                 // nothing in flight may still read the chunks
     pool_trim(c);                                  // (whatever an earlier database left and nobody took)
     for (auto &ch : c->chunks) {
-        if (ch.d_tiled) c->pool.push_back({(void *)ch.d_tiled, ch.tiled_cap});
+        if (ch.d_tiled && ch.tiled_cap) c->pool.push_back({(void *)ch.d_tiled, ch.tiled_cap});      // (cap 0: a share of another piece's buffer)
         if (ch.d_len) c->pool.push_back({(void *)ch.d_len, ch.len_cap});
         if (ch.ready) (void)hipEventDestroy(ch.ready);
     }

@@ -165,12 +165,13 @@ struct ChunkRec {
     std::vector<uint32_t> own_disp;   // a piece of a caller's chunk: its groups' offsets counted from the piece's first byte (h_disp points here)
     uint32_t group_count = 0, vl = 0;
     const char *h_codes = nullptr; uint64_t code_bytes = 0;
-    std::vector<uint32_t> off;  // kind 1: residue offset of every sequence (n_seq + 1)
+    const uint16_t *h_len = nullptr;   // kind 1: the caller's lengths (the tiling kernel turns them into offsets itself)
+    std::vector<uint32_t> gsrc; // kind 1: residue offset of every device group's first sequence in h_codes (n_groups + 1)
     std::vector<uint64_t> goff; // byte offset of every device group in d_tiled
     std::vector<uint32_t> gcols;
     bool uploaded = false, lens_known = false;
     uint32_t groups_uploaded = 0;   // device groups on the device so far (a chunk may travel in parts)
-    size_t tiled_cap = 0, len_cap = 0;   // sizes of the two device buffers (they go back to the context's pool)
+    size_t tiled_cap = 0, len_cap = 0;   // sizes of the two device buffers (they go back to the context's pool); tiled_cap 0: d_tiled is a share of another piece's buffer
     hipEvent_t ready = nullptr; // recorded on the upload stream behind the chunk's (re-)tile kernel
 };
 
@@ -228,6 +229,7 @@ struct swimm_hip_ctx {
     bool batch_now = false;             // the search in progress runs its non-rotated queries as group-resident batch launches
     std::vector<uint8_t> stream_tail;   // streaming search: the tail flags of the whole database (pick_tail)
     bool streaming_now = false;         // the search in progress streams its database in (per-range launches, no group-resident batches)
+    double add_seconds = 0;             // host time spent in add_chunk / add_sequences since the last search (reported under SWIMM_HIP_DEBUG)
     bool tiling_room = false;           // ... and the launch shapes being chosen must leave the tiling waves their registers (plan.cpp, choose_plan)
     DevBuf<QDesc> d_qdesc;              // group-resident launches: per batch, its queries
     DevBuf<uint32_t> d_wave_out;        // stacks of short queries: per (stack, wave) the first element of the wave's member's score row
@@ -266,7 +268,7 @@ struct swimm_hip_ctx {
     std::vector<ChunkRec> chunks;
     std::vector<GroupDesc> groups;
     std::vector<uint64_t> group_col_off;
-    std::vector<uint32_t> seq_len;      // true length of every local slot (from the re-tile kernel)
+    std::vector<uint16_t> seq_len;      // true length of every local slot (.seq slabs: as handed over; chunk layout: from the re-tile kernel)
     uint64_t total_cols = 0;
     bool groups_dirty = true;
     std::map<int, DbPlan> plans;        // key: n_wg (packed mode), n_wg | 1<<30 (whole-db int32 mode)

@@ -49,13 +49,16 @@ int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const uint16_t *lens_or_null
     const uint32_t dev_groups = rec.n_groups;
     uint64_t bytes = 0;
     for (uint32_t g = 0; g < dev_groups; ++g) { rec.goff[g] = bytes; bytes += (uint64_t)rec.gcols[g] * kGroupSeqs; }
-    if (pool_alloc(c, std::max<uint64_t>(bytes, 16), (void **)&rec.d_tiled, &rec.tiled_cap)) return 1;
+    const bool own = rec.d_tiled == nullptr;               // (else: the caller's share of a slab's buffer, swimm_hip_add_sequences)
+    if (own && pool_alloc(c, std::max<uint64_t>(bytes, 16), (void **)&rec.d_tiled, &rec.tiled_cap)) return 1;
     if (rec.kind == 0 && pool_alloc(c, (size_t)dev_groups * kGroupSeqs * sizeof(uint32_t), (void **)&rec.d_len, &rec.len_cap)) {
-        (void)hipFree(rec.d_tiled); rec.d_tiled = nullptr;
+        if (own) (void)hipFree(rec.d_tiled);
+        rec.d_tiled = nullptr;
         return 1;
     }
     if (hipEventCreateWithFlags(&rec.ready, hipEventDisableTiming) != hipSuccess) {
-        (void)hipFree(rec.d_tiled); (void)hipFree(rec.d_len);
+        if (own) (void)hipFree(rec.d_tiled);
+        (void)hipFree(rec.d_len);
         return fail("hipEventCreate failed");
     }
     rec.group0 = (uint32_t)c->groups.size();
@@ -70,9 +73,8 @@ int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const uint16_t *lens_or_null
         c->total_cols += rec.gcols[g];
         rec.cols += rec.gcols[g];
     }
-    const size_t base = c->seq_len.size();
-    c->seq_len.resize(base + (size_t)dev_groups * kGroupSeqs, 0);
-    for (uint64_t i = 0; i < n_lens; ++i) c->seq_len[base + i] = lens_or_null[i];
+    if (lens_or_null) c->seq_len.insert(c->seq_len.end(), lens_or_null, lens_or_null + n_lens);      // (one pass, no zero fill first)
+    c->seq_len.resize((size_t)(rec.group0 + dev_groups) * kGroupSeqs, 0);
     rec.lens_known = rec.kind == 1;
     c->chunks.push_back(std::move(rec));
     c->groups_dirty = true;
@@ -122,16 +124,18 @@ int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEven
                               r.d_len + (size_t)g0 * kGroupSeqs, s));
     } else {
         const uint64_t s0 = (uint64_t)g0 * kGroupSeqs, s1 = std::min<uint64_t>(r.n_seq, (uint64_t)g1 * kGroupSeqs);
-        const uint32_t o0 = r.off[s0], o1 = r.off[s1];
+        const uint32_t o0 = r.gsrc[g0], o1 = r.gsrc[g1];
         bytes = o1 - o0;
         HIP_TRY(c->up_b.reserve(std::max<uint64_t>(bytes, 16)));
-        HIP_TRY(c->up_off.reserve(s1 - s0 + 1));
-        HIP_TRY(hipMemcpyAsync(c->up_off.p, r.off.data() + s0, (s1 - s0 + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(c->up_off.reserve(dev_groups));
+        HIP_TRY(c->up_n.reserve(s1 - s0));
+        HIP_TRY(hipMemcpyAsync(c->up_off.p, r.gsrc.data() + g0, dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->up_n.p, r.h_len + s0, (s1 - s0) * sizeof(uint16_t), hipMemcpyHostToDevice, s));
         t_a = now_s();
         HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_codes + o0, bytes, hipMemcpyHostToDevice, s));
         t_b = now_s();
         HIP_TRY(hipEventRecord(c->ev_copied, s));
-        HIP_TRY(launch_tile_sequences(c->up_b.p - o0, c->up_off.p, (uint32_t)(s1 - s0), c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled, s));
+        HIP_TRY(launch_tile_sequences(c->up_b.p - o0, c->up_n.p, c->up_off.p, (uint32_t)(s1 - s0), c->up_goff.p, c->up_gcols.p, dev_groups, max_cols, r.d_tiled, s));
     }
     HIP_TRY(hipEventRecord(ready ? ready : r.ready, s));
     t_c = now_s();
@@ -145,8 +149,8 @@ int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEven
     r.groups_uploaded += dev_groups;
     if (r.groups_uploaded >= r.n_groups) {
         r.uploaded = true;
-        r.h_b = nullptr; r.h_n = nullptr; r.h_disp = nullptr; r.h_codes = nullptr;
-        std::vector<uint32_t>().swap(r.off);
+        r.h_b = nullptr; r.h_n = nullptr; r.h_disp = nullptr; r.h_codes = nullptr; r.h_len = nullptr;
+        std::vector<uint32_t>().swap(r.gsrc);
     }
     return 0;
 }
@@ -168,15 +172,15 @@ int ensure_uploader(swimm_hip_ctx *c)
 int sync_lengths(swimm_hip_ctx *c)
 {
     CHECK_DEVICE(c);
-    bool any = false;
     for (ChunkRec &r : c->chunks) {
         if (r.lens_known || !r.uploaded) continue;
-        HIP_TRY(hipMemcpyAsync(c->seq_len.data() + (size_t)r.group0 * kGroupSeqs, r.d_len, (size_t)r.n_groups * kGroupSeqs * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, c->stream_up));
+        const size_t n = (size_t)r.n_groups * kGroupSeqs;
+        std::vector<uint32_t> wide(n);
+        HIP_TRY(hipMemcpyAsync(wide.data(), r.d_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream_up));
+        HIP_TRY(hipStreamSynchronize(c->stream_up));
+        for (size_t i = 0; i < n; ++i) c->seq_len[(size_t)r.group0 * kGroupSeqs + i] = (uint16_t)wide[i];
         r.lens_known = true;
-        any = true;
     }
-    if (any) HIP_TRY(hipStreamSynchronize(c->stream_up));
     return 0;
 }
 

@@ -135,7 +135,7 @@ class HipSearcher:
         """sorted sequences as the .seq file stores them (lengths + concatenated codes): tiled on the device"""
         lengths = np.ascontiguousarray(lengths, dtype=np.uint16)
         codes = np.ascontiguousarray(codes, dtype=np.int8)
-        if int(lengths.astype(np.int64).sum()) != codes.size:
+        if int(np.sum(lengths, dtype=np.int64)) != codes.size:
             raise ValueError("lengths do not add up to the number of codes")
         self._keep.append((lengths, codes))
         _check(self._L.swimm_hip_add_sequences(self._ctx, _p(lengths), _p(codes), C.c_uint64(len(lengths)), C.c_uint64(first_seq)))

@@ -38,9 +38,12 @@ with hip_backend.HipSearcher(0) as s:
         s.set_option(k, int(v))
     upload(s)
     for rep in range(2):
+        if rep == 1 and os.environ.get("SWIMM_TL_DEBUG_RESIDENT"):
+            os.environ["SWIMM_HIP_DEBUG"] = "1"
         t = time.time()
         s.search_topr(20, db.n)
         dt = time.time() - t
+        os.environ.pop("SWIMM_HIP_DEBUG", None)
         print(f"resident search {rep}: {dt * 1e3:.2f} ms -> {cells / dt / 1e9:.0f} GCUPS; device {s.last_stats()['kernel_ms']:.2f} ms, {s.last_stats()['launches']} launches", file=sys.stderr)
     for rep in range(2):
         s.clear_db()

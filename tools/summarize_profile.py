@@ -98,6 +98,9 @@ def main():
             "WRITE_SIZE_KB": write,
             "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on coalesced streaming reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact. The guide calibrates 16 B/lane; this kernel loads 8 B/lane (dwordx2), calibrated here on its known byte counts: x2 reproduces them within 3 % in the one-pass launch (DB bytes only) and within 1 % in the two-pass launch (DB + boundary bytes)",
             "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+            # a query batch: every DP kernel dispatch of the run (pipeline + lane-systolic), same corrections, / its searches
+            "hbm_bytes_per_search": ((2.0 * per_dp["FETCH_SIZE"] + per_dp["WRITE_SIZE"]) * 1024.0 / line["searches_in_run"])
+                                    if line.get("searches_in_run") and per_dp.get("FETCH_SIZE") and per_dp.get("WRITE_SIZE") else None,
             "grbm_gui_active_sum_over_8_xcd": mean("GRBM_GUI_ACTIVE"),
         }
         json.dump(traffic, open(os.path.join(out, f"{rnd}_pmc_traffic_{label}.json"), "w"), indent=1)

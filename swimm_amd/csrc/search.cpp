@@ -1601,7 +1601,9 @@ int SearchRun::drain()
     HIP_TRY(hipEventRecord(c->ev_tail3, c->stream3));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tail3, 0));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    const double t_drain = now_s();
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (dbg) fprintf(stderr, "swimm_hip: drain entered %.3f ms after the call began, every stream drained at %.3f ms\n", (t_drain - t_begin) * 1e3, (now_s() - t_begin) * 1e3);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->kernel_ms += ms;
@@ -1634,6 +1636,7 @@ int SearchRun::drain()
     if (werr) return fail("pipeline watchdog expired (code %u): results discarded", werr);
     if (streaming) { release_plans(c); c->groups_dirty = true; }   // (the cached lists of the resident database are built on the next search)
     pool_trim(c);                      // (buffers of a cleared database that the new chunks did not take: freed now, not at the start of a search)
+    if (dbg) fprintf(stderr, "swimm_hip: drain left %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
     return 0;
 }
 

@@ -435,6 +435,7 @@ int swimm_hip_search_topr(swimm_hip_ctx *c, uint32_t r, uint64_t n_valid, int32_
         const uint32_t qe = std::min(qtotal, qb + B), qn = qe - qb;
         uint64_t S = 0;
         if (search_device(c, qb, qe, &S)) return 1;
+        if (getenv("SWIMM_HIP_DEBUG")) fprintf(stderr, "swimm_hip: search_topr: scores on the device %.3f ms after the call\n", (now_s() - t0) * 1e3);
         int32_t *out_s = top_scores + (size_t)qb * r;
         int64_t *out_i = top_index + (size_t)qb * r;
         // the device keys carry the global index in 32 bits (score << 32 | index, + 1): a database part whose indices do not
@@ -501,6 +502,7 @@ int swimm_hip_search_topr(swimm_hip_ctx *c, uint32_t r, uint64_t n_valid, int32_
             }
         }
     }
+    if (getenv("SWIMM_HIP_DEBUG")) fprintf(stderr, "swimm_hip: search_topr: lists selected %.3f ms after the call\n", (now_s() - t0) * 1e3);
     if (work_time) *work_time = now_s() - t0;
     return 0;
 }

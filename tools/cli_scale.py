@@ -25,6 +25,7 @@ scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 SWIMM = os.path.join(ROOT, "swimm_amd", "bin", "swimm")
 res = {"config": "c5 (Env-NR shape, 20 queries, PAM250 10/2, top 20)", "scale": scale}
 tmpdir = os.environ.get("SWIMM_SCALE_TMP") or tempfile.mkdtemp(prefix="swimm_cli_scale_")
+os.makedirs(tmpdir, exist_ok=True)
 fa, qfa, prefix = os.path.join(tmpdir, "db.fa"), os.path.join(tmpdir, "q.fa"), os.path.join(tmpdir, "db")
 
 t0 = time.time()

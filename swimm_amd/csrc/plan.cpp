@@ -121,6 +121,7 @@ int list_copy(swimm_hip_ctx *c, void *dst, const void *src, size_t bytes)
     c->pin_used += (bytes + 255) & ~(size_t)255;
     return 0;
 }
+AllocStats g_alloc_stats;
 double g_list_sync_wait_s = 0;          // (debug aid: seconds the host spent in list_sync since it was last zeroed)
 int list_sync(swimm_hip_ctx *c)
 {

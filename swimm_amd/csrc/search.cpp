@@ -1057,7 +1057,9 @@ int SearchRun::size_buffers()
     // buffers that later launches grow are sized up front: a reallocation in the middle of the
     // multi-stream phase would free memory a kernel in flight still uses
     {
-        uint64_t need_bnd = 0;
+        uint64_t need_bnd = 0;          // the per-pass launches' boundary rows (and, resident database, a batch's)
+        uint64_t need_res = 0;          // streaming: the group-resident range launches' boundary scratch, on three buffers in rotation
+        bool pp_on_b = false;           // streaming: some per-pass launches run on stream B with the second buffer
         size_t tail_cols = 0, tail_items = 0, launch_total = 16;
         int max_passes = 1;
         for (uint32_t q = 0; q < qn; ++q) max_passes = std::max(max_passes, (int)((qm[q] + 64 * kLaneRows - 1) / (64 * kLaneRows)));
@@ -1087,9 +1089,12 @@ int SearchRun::size_buffers()
                     int per_cu = 1;
                     if (wgs_per_cu(c, main_mode, qp.T, qp.W, res_of(ri, q), &per_cu)) return 1;
                     const uint64_t cols = ranges[ri].cols * (main_mode == Mode::I32 ? 2 : 1);
-                    if (res_of(ri, q)) need_bnd = std::max<uint64_t>(need_bnd, (uint64_t)n_workgroups(c, per_cu) * longest_all * 64);   // (a batch takes every group)
+                    if (res_of(ri, q)) need_res = std::max<uint64_t>(need_res, (uint64_t)n_workgroups(c, per_cu) * longest_all * 64);   // (a batch takes every group)
                     // (only the dynamic queue's list is cut into runs that fit the budget: the static partition takes the range whole)
-                    else need_bnd = std::max<uint64_t>(need_bnd, (c->opt_dynamic ? std::min<uint64_t>(cols, std::max<uint64_t>(budget, longest_main)) : cols) * 64);
+                    else {
+                        need_bnd = std::max<uint64_t>(need_bnd, (c->opt_dynamic ? std::min<uint64_t>(cols, std::max<uint64_t>(budget, longest_all)) : cols) * 64);
+                        pp_on_b = pp_on_b || (pp_range(ri) ? alternate_pp : (ri & 1) != 0);      // (issue(): which stream a per-pass launch of this range takes)
+                    }
                     // (runs of the boundary buffer: the greedy cut closes a run when the next item would overflow it, so two
                     // consecutive runs together exceed the budget -- at most 2 cols / budget + 1 of them, and never more than items)
                     const uint64_t items = (uint64_t)(ranges[ri].g1 - ranges[ri].g0) * (main_mode == Mode::I32 ? 2 : 1);
@@ -1111,7 +1116,14 @@ int SearchRun::size_buffers()
                         boundary_segments(c, dp->main, segs, &cols);
                         nsegs = segs.size();
                     }
-                    need_bnd = std::max<uint64_t>(need_bnd, cols * 64);
+                    // ... rounded up to what a search that STREAMS the same database in reserves from the geometry alone (below: all the
+                    // groups' columns, or the budget when the list is cut into runs): the database that replaces this one finds the
+                    // buffer large enough (a run is up to one item short of the budget: the 17 GB buffer of c4 was freed and allocated
+                    // again for 0.2 % more, 1 s inside the first cold search)
+                    const uint32_t longest = longest_cols;          // (plan_queries: the longest group of the database)
+                    const uint64_t all = c->total_cols * (main_mode == Mode::I32 ? 2 : 1);
+                    const uint64_t bound = c->opt_dynamic ? std::min<uint64_t>(all, std::max<uint64_t>(bnd_budget_cols(c), longest)) : all;
+                    need_bnd = std::max<uint64_t>(need_bnd, std::max<uint64_t>(cols, bound) * 64);
                 }
                 launch_total += (size_t)qps[q].passes * std::max<size_t>(nsegs, 2);   // two kernels per pass when the list is split over two streams
                 tail_cols = std::max<size_t>(tail_cols, dp->tail.cols);
@@ -1124,9 +1136,11 @@ int SearchRun::size_buffers()
                 for (const Range &rg : ranges) need_bnd = std::max<uint64_t>(need_bnd, rg.cols * 64);
         }
         if (dbg) fprintf(stderr, "swimm_hip: buffer sizes known %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
-        HIP_TRY(c->d_bnd.reserve(need_bnd));
-        if (alternate || c->batch_now || (streaming && !one_list)) HIP_TRY(c->d_bnd_b.reserve(need_bnd));
-        if (c->batch_now && streaming) HIP_TRY(c->d_bnd_c.reserve(need_bnd));
+        // (round 4, first version: all three buffers at the per-pass size -- 3 x 17 GB for c4's last range, 0.97 s of hipMalloc inside
+        // the first cold search -- where the group-resident ranges that take turns on them need 0.3 GB each)
+        HIP_TRY(c->d_bnd.reserve(std::max(need_bnd, need_res)));
+        if (alternate || c->batch_now || (streaming && !one_list)) HIP_TRY(c->d_bnd_b.reserve(std::max(streaming && !pp_on_b ? (uint64_t)0 : need_bnd, need_res)));
+        if (c->batch_now && streaming) HIP_TRY(c->d_bnd_c.reserve(std::max<uint64_t>(need_res, 1)));
         HIP_TRY(c->d_queue.reserve(launch_total));           // one zeroed queue cursor per pipeline launch of this search
         HIP_TRY(hipMemsetAsync(c->d_queue.p, 0, launch_total * sizeof(uint32_t), c->stream));
         c->queue_next = 0;
@@ -1636,7 +1650,9 @@ int SearchRun::drain()
     if (werr) return fail("pipeline watchdog expired (code %u): results discarded", werr);
     if (streaming) { release_plans(c); c->groups_dirty = true; }   // (the cached lists of the resident database are built on the next search)
     pool_trim(c);                      // (buffers of a cleared database that the new chunks did not take: freed now, not at the start of a search)
-    if (dbg) fprintf(stderr, "swimm_hip: drain left %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
+    if (dbg) fprintf(stderr, "swimm_hip: drain left %.3f ms after the call began; device allocations since the last search: %u calls, %.1f MB, %.3f ms\n", (now_s() - t_begin) * 1e3,
+                     g_alloc_stats.calls, g_alloc_stats.bytes / 1e6, g_alloc_stats.seconds * 1e3);
+    g_alloc_stats = AllocStats{};
     return 0;
 }
 

@@ -177,6 +177,8 @@ hipError_t launch_tile_sequences(const uint8_t *codes, const uint16_t *lens /* [
 // appends the slots whose score is >= thr (tier left its exact range) to list (up to cap) and zeroes them
 // items of a streaming search's list that are on the device (PipeParams::avail); kAvailAbort = the upload failed: give up
 constexpr uint32_t kAvailAbort = 0xFFFFFFFFu;
+// one wave that lasts `microseconds` and does nothing (probe: do two streams share a hardware queue?)
+hipError_t launch_spin(uint32_t microseconds, hipStream_t s);
 hipError_t launch_publish_items(uint32_t *avail, uint32_t value, hipStream_t s);
 hipError_t launch_collect_saturated(int32_t *scores, uint64_t n, int thr, uint32_t *list, uint32_t *count, uint32_t cap, hipStream_t s);
 // per-block top-64 candidates of every query's score row (rows n_slots apart): out_keys[(query * n_blocks + block) * 64 + i] =

@@ -1483,6 +1483,19 @@ hipError_t launch_publish_items(uint32_t *avail, uint32_t value, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- a kernel that only lasts (swimm_hip.cpp, make_streams: which streams share a hardware queue) ----
+__global__ void spin_kernel(uint32_t ticks)          // ticks of the 100 MHz constant clock
+{
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+hipError_t launch_spin(uint32_t microseconds, hipStream_t s)
+{
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, microseconds * 100u);
+    return hipGetLastError();
+}
+
 // ---- saturation bookkeeping ----------------------------------------------------------------
 // list[i] = slots whose first-tier best left the tier's exact range (>= thr: 32767 for int16, CPUsearch.c:820-824
 // "overflow detection"; 2048 for f16);

@@ -79,28 +79,55 @@ int swimm_hip_bind_host_thread(int device, int num_devices, char *cpulist_out, s
 }
 
 // The context's streams and the hardware queues behind them.  The runtime multiplexes the streams of one priority class onto a
-// pool of four hardware queues (first use takes a queue of its own while the pool is not full, then the least-used one), and a
-// packet waits for everything in front of it in ITS hardware queue: a work-list copy on a stream that shared a queue with a
-// group-resident range launch waited 60-400 ms for that launch to end (r04, c4 / c5 cold; profiles/NOTES.md).  So
+// pool of four hardware queues, and a packet waits for everything in front of it in ITS hardware queue: a work-list copy on a
+// stream that shared a queue with a group-resident range launch waited 60-400 ms for that launch to end, and in the second
+// context of a process the upload stream did -- the 7 GB of c4 landed after 447 ms instead of 153 (r04; profiles/NOTES.md).  So
 //   - the work-list stream is of the HIGH priority class: a pool of its own, never behind a launch stream;
 //   - the upload stream stays in the normal class (in a class of its own every copy -> tile -> publish step of the one-launch
-//     search cost more: c2 cold 27.5 -> 28.7 ms) but is the FIRST stream of the context to be used, then the three launch
-//     streams: each of the four takes a queue of its own where the process holds no other stream, and when it does (torch's null
-//     stream in bench.py) the one that has to share is the ladder stream, which runs when the uploads are over.
+//     search cost more: c2 cold 27.5 -> 28.7 ms), and which queue it got is MEASURED: a wave that only lasts 400 us goes to each of
+//     the three launch streams in turn and a 64-byte fill to the candidate; a fill that takes as long as the wave shares its queue.
+//     A candidate that shares is set aside (alive, so that the next one is dealt another queue) and the next one tried.  Which
+//     stream lands on which queue depends on what else the process has created and released; the probe does not.
 static hipError_t make_streams(swimm_hip_ctx *c)
 {
     int lo = 0, hi = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (e != hipSuccess) return e;
-    if ((e = hipStreamCreate(&c->stream_up)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream_b)) != hipSuccess ||
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream_b)) != hipSuccess ||
         (e = hipStreamCreate(&c->stream2)) != hipSuccess || (e = hipStreamCreate(&c->stream3)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&c->stream_list, hipStreamDefault, hi)) != hipSuccess) return e;
     void *tmp = nullptr;
     if ((e = hipMalloc(&tmp, 256)) != hipSuccess) return e;
-    for (hipStream_t st : {c->stream_up, c->stream, c->stream_b, c->stream2, c->stream3, c->stream_list}) {      // first use, in this order
-        if ((e = hipMemsetAsync(tmp, 0, 64, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) break;
+    auto touch = [&](hipStream_t st) { hipError_t r = hipMemsetAsync(tmp, 0, 64, st); return r != hipSuccess ? r : hipStreamSynchronize(st); };
+    for (hipStream_t st : {c->stream, c->stream_b, c->stream2, c->stream3, c->stream_list})
+        if ((e = touch(st)) != hipSuccess) { (void)hipFree(tmp); return e; }
+    const bool dbg = getenv("SWIMM_HIP_DEBUG") != nullptr || getenv("SWIMM_HIP_DEBUG_STREAMS") != nullptr;
+    std::vector<hipStream_t> aside;
+    hipStream_t best = nullptr;
+    for (int attempt = 0; attempt < 8 && e == hipSuccess; ++attempt) {
+        hipStream_t cand = nullptr;
+        if ((e = hipStreamCreate(&cand)) != hipSuccess || (e = touch(cand)) != hipSuccess) { if (cand) aside.push_back(cand); break; }
+        bool shares = false;
+        for (hipStream_t launch : {c->stream, c->stream_b, c->stream2}) {
+            if ((e = launch_spin(400, launch)) != hipSuccess) break;
+            const double t0 = now_s();
+            if ((e = touch(cand)) != hipSuccess) break;
+            const double dt = now_s() - t0;
+            if ((e = hipStreamSynchronize(launch)) != hipSuccess) break;
+            if (dt > 250e-6) { shares = true; break; }
+        }
+        if (e != hipSuccess) { aside.push_back(cand); break; }
+        if (dbg) fprintf(stderr, "swimm_hip: upload stream candidate %d %s a hardware queue with a launch stream\n", attempt, shares ? "shares" : "does not share");
+        if (!shares) { best = cand; break; }
+        aside.push_back(cand);
     }
+    if (e == hipSuccess && !best) {          // (every normal-class queue is behind a launch stream: a class of its own after all)
+        e = hipStreamCreateWithPriority(&best, hipStreamDefault, lo);
+        if (e == hipSuccess) e = touch(best);
+    }
+    for (hipStream_t st : aside) (void)hipStreamDestroy(st);
     (void)hipFree(tmp);
+    c->stream_up = best;
     return e;
 }
 
@@ -167,6 +194,7 @@ void swimm_hip_destroy(swimm_hip_ctx *c)
     c->d_scores.release(); c->d_prof.release(); c->d_bnd.release(); c->d_bnd_b.release(); c->d_bnd_c.release(); c->d_avail.release(); c->d_stream_items.release();
     if (c->list_arena.base) { (void)hipFree(c->list_arena.base); c->list_arena = DevArena{}; } c->d_qcodes.release(); c->d_sub16.release(); c->d_qdesc.release(); c->d_wave_out.release();
     if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = c->pin_used = 0; }
+    if (c->up_pin) { (void)hipHostFree(c->up_pin); c->up_pin = nullptr; c->up_pin_cap = c->up_pin_used = 0; }
     c->d_gbase.release(); c->d_gvalid.release(); c->d_keys.release(); c->d_err.release(); c->tail_scratch.release(); c->tail_scratch_t[0].release(); c->tail_scratch_t[1].release(); c->rerun_scratch.release(); c->d_rerun_items.release(); c->d_satlist.release(); c->d_ladder_counts.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

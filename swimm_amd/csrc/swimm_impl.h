@@ -69,6 +69,11 @@ struct DevArena {
 };
 extern thread_local DevArena *g_list_arena;
 
+// (debug aid: device allocations made through DevBuf since the counters were last zeroed -- what a search allocates is on its clock)
+struct AllocStats { double seconds = 0; size_t bytes = 0; unsigned calls = 0; };
+extern AllocStats g_alloc_stats;
+inline double alloc_now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 template <class T>
 struct DevBuf {   // grow-only device scratch
     T *p = nullptr;
@@ -84,10 +89,12 @@ struct DevBuf {   // grow-only device scratch
                 return hipSuccess;
             }
         }
+        const double t0 = alloc_now_s();
         if (p && !borrowed) { hipError_t e = hipFree(p); if (e != hipSuccess) { p = nullptr; cap = 0; return e; } }
         p = nullptr; cap = 0; borrowed = false;
         hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
         if (e == hipSuccess) cap = n;
+        g_alloc_stats.seconds += alloc_now_s() - t0; g_alloc_stats.bytes += n * sizeof(T); g_alloc_stats.calls++;
         return e;
     }
     void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
@@ -209,6 +216,7 @@ struct swimm_hip_ctx {
     hipStream_t stream_up = nullptr;    // uploads: H2D copies, (re-)tile kernels -- never waits for a DP kernel
     hipStream_t stream_list = nullptr;  // work lists (list_copy)
     hipEvent_t ev_copied = nullptr;
+    void *up_pin = nullptr; size_t up_pin_cap = 0, up_pin_used = 0;      // pinned staging of a part's small arrays (upload_part)
     DevBuf<uint8_t> up_b; DevBuf<uint16_t> up_n; DevBuf<uint32_t> up_disp, up_gcols, up_off; DevBuf<uint64_t> up_goff;   // upload scratch, reused chunk after chunk
     int opt_upload_piece_kib = 98304;   // lazy_upload: chunks and slabs larger than this are recorded in pieces of about this size (96 MiB, the reference's chunk size)
     int opt_lazy_upload = 0;            // 1: add_chunk / add_sequences record the caller's buffers, the first search streams them in

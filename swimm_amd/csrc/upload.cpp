@@ -25,6 +25,8 @@ int pool_alloc(swimm_hip_ctx *c, size_t bytes, void **out, size_t *cap)
         c->pool.erase(c->pool.begin() + best);
         return 0;
     }
+    const double t0 = now_s();
+    struct Tm { double t0; size_t b; ~Tm() { g_alloc_stats.seconds += now_s() - t0; g_alloc_stats.bytes += b; g_alloc_stats.calls++; } } tm{t0, bytes};
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipErrorOutOfMemory && !c->pool.empty()) {      // the pool still holds what the old database left: hand it back and try again
         (void)hipGetLastError();
@@ -38,7 +40,10 @@ int pool_alloc(swimm_hip_ctx *c, size_t bytes, void **out, size_t *cap)
 
 void pool_trim(swimm_hip_ctx *c)
 {
+    if (c->pool.empty()) return;
+    const double t0 = now_s();
     for (auto &b : c->pool) (void)hipFree(b.first);
+    g_alloc_stats.seconds += now_s() - t0; g_alloc_stats.calls += (unsigned)c->pool.size();
     c->pool.clear();
 }
 
@@ -88,6 +93,33 @@ int register_chunk(swimm_hip_ctx *c, ChunkRec &rec, const uint16_t *lens_or_null
 // part after part (the stream is in order: the next copy cannot overtake this part's kernel).  The kernels index groups,
 // lane groups and sequences from 0: a part hands them its own slices, and the byte / residue offsets inside those slices
 // stay absolute, so the scratch pointer is moved back by the part's first byte.
+// A part's small arrays (group geometry, lengths, offsets) go through pinned staging: from pageable memory each of them is a
+// blocking copy of 30-50 us, four or five per part and 21 parts for c2 -- 3.5 ms of a 14 ms upload (r04: the chunk layout's
+// host copies ended 17 ms after the call, the slabs' 13.3 ms).  The staging is reused part after part: upload_part ends with a
+// wait for ev_copied, behind these copies on the stream.
+static int stage_small(swimm_hip_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return 0;
+    const size_t at = (c->up_pin_used + 63) & ~(size_t)63;
+    if (at + bytes > c->up_pin_cap) return fail("internal: upload staging of %zu bytes too small for %zu more", c->up_pin_cap, bytes);
+    memcpy((char *)c->up_pin + at, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, (char *)c->up_pin + at, bytes, hipMemcpyHostToDevice, s));
+    c->up_pin_used = at + bytes;
+    return 0;
+}
+
+static int reserve_staging(swimm_hip_ctx *c, size_t need, hipStream_t s)
+{
+    c->up_pin_used = 0;
+    if (need <= c->up_pin_cap) return 0;
+    HIP_TRY(hipStreamSynchronize(s));
+    if (c->up_pin) { HIP_TRY(hipHostFree(c->up_pin)); c->up_pin = nullptr; c->up_pin_cap = 0; }
+    const size_t cap = std::max<size_t>(need + need / 2, (size_t)1 << 20);
+    HIP_TRY(hipHostMalloc(&c->up_pin, cap, hipHostMallocDefault));
+    c->up_pin_cap = cap;
+    return 0;
+}
+
 int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEvent_t ready)
 {
     if (r.uploaded || g0 >= g1) return 0;
@@ -102,8 +134,13 @@ int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEven
     uint64_t bytes = 0;
     HIP_TRY(c->up_gcols.reserve(dev_groups));
     HIP_TRY(c->up_goff.reserve(dev_groups));
-    HIP_TRY(hipMemcpyAsync(c->up_gcols.p, r.gcols.data() + g0, dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->up_goff.p, r.goff.data() + g0, dev_groups * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    {
+        const uint32_t per = r.kind == 0 ? kGroupSeqs / r.vl : 0;
+        const size_t small = r.kind == 0 ? (size_t)(std::min(r.group_count, g1 * per) - g0 * per) * 6 : (size_t)dev_groups * 4 + (size_t)dev_groups * kGroupSeqs * 2;
+        if (reserve_staging(c, (size_t)dev_groups * 12 + small + 1024, s)) return 1;
+    }
+    if (stage_small(c, c->up_gcols.p, r.gcols.data() + g0, dev_groups * sizeof(uint32_t), s) ||
+        stage_small(c, c->up_goff.p, r.goff.data() + g0, dev_groups * sizeof(uint64_t), s)) return 1;
     if (r.kind == 0) {
         const uint32_t per = kGroupSeqs / r.vl;
         const uint32_t v0 = g0 * per, v1 = std::min(r.group_count, g1 * per);
@@ -114,8 +151,7 @@ int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEven
         HIP_TRY(c->up_n.reserve(v1 - v0));
         HIP_TRY(c->up_disp.reserve(v1 - v0));
         HIP_TRY(hipMemsetAsync(r.d_len + (size_t)g0 * kGroupSeqs, 0, (size_t)dev_groups * kGroupSeqs * sizeof(uint32_t), s));
-        HIP_TRY(hipMemcpyAsync(c->up_n.p, r.h_n + v0, (v1 - v0) * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->up_disp.p, r.h_disp + v0, (v1 - v0) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        if (stage_small(c, c->up_n.p, r.h_n + v0, (v1 - v0) * sizeof(uint16_t), s) || stage_small(c, c->up_disp.p, r.h_disp + v0, (v1 - v0) * sizeof(uint32_t), s)) return 1;
         t_a = now_s();
         HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_b + b0, bytes, hipMemcpyHostToDevice, s));
         t_b = now_s();
@@ -129,8 +165,7 @@ int upload_part(swimm_hip_ctx *c, ChunkRec &r, uint32_t g0, uint32_t g1, hipEven
         HIP_TRY(c->up_b.reserve(std::max<uint64_t>(bytes, 16)));
         HIP_TRY(c->up_off.reserve(dev_groups));
         HIP_TRY(c->up_n.reserve(s1 - s0));
-        HIP_TRY(hipMemcpyAsync(c->up_off.p, r.gsrc.data() + g0, dev_groups * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->up_n.p, r.h_len + s0, (s1 - s0) * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        if (stage_small(c, c->up_off.p, r.gsrc.data() + g0, dev_groups * sizeof(uint32_t), s) || stage_small(c, c->up_n.p, r.h_len + s0, (s1 - s0) * sizeof(uint16_t), s)) return 1;
         t_a = now_s();
         HIP_TRY(hipMemcpyAsync(c->up_b.p, r.h_codes + o0, bytes, hipMemcpyHostToDevice, s));
         t_b = now_s();

@@ -48,7 +48,7 @@ with hip_backend.HipSearcher(0) as s:
     for rep in range(2):
         s.clear_db()
         s.set_option("lazy_upload", 1)
-        if rep == 1:
+        if rep == 1 or os.environ.get("SWIMM_TL_DEBUG_ALL"):
             os.environ["SWIMM_HIP_DEBUG"] = "1"
         t = time.time()
         upload(s)

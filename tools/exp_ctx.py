@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Cold searches in the SECOND and THIRD context of a process (bench.py runs one context per configuration): c2 through chunks, then
-c5 at 10 % through slabs; prints add + search ms and the resident ms beside them."""
+a BASELINE configuration through slabs (default c5 at 10 %); prints add + search ms and the resident ms beside them.
+usage: python tools/exp_ctx.py [c3|c4|c5] [scale]     (EXP_DEBUG=1: the library's timeline of the last cold search of the slab contexts)"""
 import os, sys, time
 import numpy as np
 import torch
@@ -14,7 +15,9 @@ shard = bench.build_shard(2, 1.0)
 chunks = host.Chunks(shard["lengths"], shard["codes"], 128, 96 << 20)
 q = shard["query"]; sm = submat.table("blosum62")
 m, disp = np.array([len(q)], np.uint16), np.array([0, len(q)], np.uint32)
-db = workloads.SortedDb("c5", 0.1)
+NAME = sys.argv[1] if len(sys.argv) > 1 else "c5"
+SCALE = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
+db = workloads.SortedDb(NAME, SCALE)
 slabs = db.slabs(8); codes = [db.codes(s0, s1) for s0, s1, _ in slabs]
 sm5 = submat.table(db.matrix)
 
@@ -46,7 +49,7 @@ def c5_ctx(tag):
             for (s0, s1, _), c in zip(slabs, codes): s.add_sequences(db.lengths[s0:s1], c, first_seq=s0)
             s.search_topr(20, db.n); out.append((time.time() - t) * 1e3)
             os.environ.pop("SWIMM_HIP_DEBUG", None)
-        print(f"{tag}: c5 at 10 % resident {res * 1e3:.1f} ms, cold {[round(x, 1) for x in out]}", file=sys.stderr)
+        print(f"{tag}: {NAME} at {SCALE} resident {res * 1e3:.1f} ms, cold {[round(x, 1) for x in out]}", file=sys.stderr)
 
 
 c2_ctx("context 1"); c5_ctx("context 2"); c2_ctx("context 3"); c5_ctx("context 4")

@@ -52,6 +52,10 @@ import subprocess
 import sys
 import time
 
+# (the CPU checker's OpenMP team -- every hardware thread of the host -- parks when a parallel region ends instead of spinning
+# on all cores into the measurement that follows it; read by libgomp when it is loaded)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -510,6 +514,7 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
     # one-shot `swimm -S search` pays: value_incl_h2d); a second one finds the device buffers in the library's pool
     # (value_incl_h2d_pooled).  N > 1 strong-scaling record: once.
     colds = []
+    time.sleep(0.25)          # (the checker's threads have parked)
     for _ in range(int(want_cold)):
         searcher.clear_db()
         searcher.set_option("lazy_upload", 1)        # chunks stream in while the search runs (what swimm_hip_search_chunks does)
@@ -714,7 +719,7 @@ def main():
                 "per_rank_kernel_gcups": [c5["valu_roofline"]["kernel_only_gcups"]],
                 "hbm_frac": c5["roofline"]["frac"] if c5["roofline"] else None,
                 "rccl_ranks": 0, "topr_exchange": "none", "bit_exact": c5["bit_exact_vs_reference"] and c5["merged_top20_matches_full_vectors"],
-                "note": "N = 1 at a quarter of the database (at N > 1 the whole 7e9-residue database is sharded: --strong-scale 1); GCUPS does not depend on the scale from 10 % up (profiles/r03_bench_c5_full.json: the whole database on one GPU)"}
+                "note": "N = 1 at a quarter of the database (at N > 1 the whole 7e9-residue database is sharded: --strong-scale 1); GCUPS does not depend on the scale from 10 % up (profiles/r04_bench_c5_full.json: the whole database on one GPU, 10 217 GCUPS)"}
         else:
             r2, ok2 = run_workload(env, args, "c5", args.strong_scale, args.secondary_steps, 1, 6.0, 0 if args.no_cold else 1, False)
             all_ok = all_ok and ok2

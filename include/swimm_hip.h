@@ -88,7 +88,9 @@ int swimm_hip_add_chunk(swimm_hip_ctx *ctx, const char *b, uint64_t vD, const ui
  * database exactly as the .seq file stores them (sequences.c:201-205) -- `lengths[i]` residues each, codes
  * concatenated -- starting at sorted index `first_seq`.  Replaces assemble_multiple_chunks_db (sequences.c:425-616)
  * + the copy above for a caller that has the preprocessed database in memory: the device builds its layout itself.
- * A slab must stay below 4 GiB of residues; every slab but the last must hold a multiple of 128 sequences. */
+ * A slab must stay below 4 GiB of residues; every slab but the last must hold a multiple of 128 sequences.
+ * Both arrays are read when the slab is copied: inside this call by default; with the option "lazy_upload" by the next search,
+ * until which BOTH `lengths` and `codes` must stay valid. */
 int swimm_hip_add_sequences(swimm_hip_ctx *ctx, const uint16_t *lengths, const char *codes, uint64_t n_seq, uint64_t first_seq);
 
 int swimm_hip_clear_db(swimm_hip_ctx *ctx);

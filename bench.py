@@ -106,8 +106,25 @@ def build_shard(seed: int, scale: float):
     return {"lengths": lens_sorted, "codes": codes, "residues": total, "n": len(lens_sorted), "query": host.recode(q_letters)}
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cfs quota); None = unlimited"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        return None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+    except (OSError, ValueError):
+        return None
+
+
 def host_cpus():
-    """(hardware threads this process may run on, physical cores they belong to)"""
+    """(threads the CPU legs should run, physical cores they amount to): the hardware threads this process may run on -- unless the
+    container's CPU quota is smaller: the GPU boxes of this pool show 256 hardware threads and grant 16 CPUs' worth of time
+    (cpu.max 1600000 100000); 256 threads then take turns on 16 CPUs (the reference: 239 GCUPS with 256 threads, 455 with 16;
+    tools/cpu_threads_probe.py) and a short run bursts past the quota (1 467 GCUPS for 30 ms with 128 threads)"""
     cpus = sorted(os.sched_getaffinity(0))
     cores = set()
     for c in cpus:
@@ -116,6 +133,10 @@ def host_cpus():
             cores.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
         except OSError:
             cores.add(("?", str(c)))
+    quota = cpu_quota()
+    if quota is not None and quota < len(cores):
+        n = max(1, int(round(quota)))
+        return n, n
     return len(cpus), len(cores)
 
 
@@ -151,7 +172,7 @@ def sample_check(qa_list, lens, codes_of, sm, threads, gpu_scores_of, budget_s, 
     -> (ok, stride, sampled sequences, sampled residues, cpu seconds, kind, inputs of the checker run)"""
     q_res = sum(len(q) for q in qa_list)
     residues = float(np.asarray(lens, dtype=np.int64).sum())
-    est = q_res * residues / (1.0e9 * max(threads, 1))       # the reference runs at about 1 GCUPS per hardware thread
+    est = q_res * residues / (12.0e9 * max(threads, 1))      # the reference runs at 14-28 GCUPS per core that is really there (host_cpus)
     stride = max(1, int(np.ceil(est / budget_s)))
     if stride == 1:
         idx = np.arange(n_total, dtype=np.int64)
@@ -644,7 +665,7 @@ def run_workload(env: Env, args, name: str, scale: float, steps: int, warmup: in
             except Exception:
                 model = "unknown"
             rec["cpu_baseline"] = {"value": round(q_real * res_s / cpu_s / 1e9, 2), "unit": "GCUPS", "cores": chk_cores, "threads": chk_threads,
-                                   "kind": kind, "cpu_model": model, "matches_gpu": ok,
+                                   "kind": kind, "cpu_model": model, "cpu_quota": cpu_quota(), "matches_gpu": ok,
                                    "sample": (f"{name} shard, " + ("every sequence" if stride == 1 else f"every {stride}th block of {SAMPLE_BLOCK} consecutive sequences") +
                                               f" ({n_s} sequences, {res_s} residues), {nq} quer{'y' if nq == 1 else 'ies'}, {cpu_s:.2f} s"),
                                    "product_m0": round(m0_gcups, 2) if m0_gcups else None,

@@ -1381,6 +1381,52 @@ __global__ void retile_kernel(const uint8_t *__restrict__ b, const uint16_t *__r
     }
 }
 
+// The same for lane widths that are multiples of 4 (every width the reference assembles): a thread takes FOUR neighbouring sequences of
+// a chunk -- four dword loads (one per column: the four sequences' residues lie side by side in the reference's layout), a byte
+// transpose (v_perm_b32), one 16-byte store -- instead of sixteen byte loads and four dword stores by four threads.  (Round 4: the
+// byte-load version took 173 us per 32 MiB part of c2 beside the pipeline kernel's waves, a fifth of the part's copy time, and the
+// next part's copy queues behind it on the upload stream.)
+__global__ void retile4_kernel(const uint8_t *__restrict__ b, const uint16_t *__restrict__ n, const uint32_t *__restrict__ disp, uint32_t vl_groups,
+                               uint32_t vl, const uint64_t *__restrict__ goff, const uint32_t *__restrict__ gcols, uint8_t *__restrict__ tiled,
+                               uint32_t *__restrict__ seq_len)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t g = blockIdx.x;
+    const uint32_t nch = gcols[g] / kChunkCols;
+    const uint32_t per = kGroupSeqs / vl;
+    for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nch * 32; idx += gridDim.y * blockDim.x) {
+        const uint32_t c = idx >> 5, sl = (idx & 31) * 4;      // sequences sl .. sl + 3 of the device group: lanes sl / 2, sl / 2 + 1
+        const uint32_t v = g * per + sl / vl, kk = sl % vl;
+        const uint32_t len = v < vl_groups ? n[v] : 0u;
+        const uint8_t *src = b + (size_t)(v < vl_groups ? disp[v] : 0u) + kk;
+        uint32_t w[kChunkCols];
+#pragma unroll
+        for (int jj = 0; jj < kChunkCols; ++jj) {
+            const uint32_t col = c * kChunkCols + jj;
+            uint32_t x = 0x18181818u;                    // PREPROCESSED_DUMMY_ELEMENT, sequences.h:18
+            if (col < len) {
+                __builtin_memcpy(&x, src + (size_t)col * vl, 4);      // (aligned whenever the groups' offsets are multiples of the lane width, as the reference's are)
+                const uint32_t over = ((x & 0x80808080u) | (((x & 0x7f7f7f7fu) + 0x67676767u) & 0x80808080u)) >> 7;   // 1 per byte > 24
+                const uint32_t m = over * 0xffu;
+                x = (x & ~m) | (0x18181818u & m);        // out-of-alphabet bytes score like padding
+            }
+            w[jj] = x;
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                    // sequence q of the four: byte q of every column's word
+            const uint32_t lo = __builtin_amdgcn_perm(w[1], w[0], 0x0c0c0000u | ((4u + q) << 8) | (uint32_t)q);
+            const uint32_t hi = __builtin_amdgcn_perm(w[3], w[2], 0x0c0c0000u | ((4u + q) << 8) | (uint32_t)q);
+            const uint32_t x = lo | (hi << 16);
+            // true length of every sequence = 1 + its last non-padding column (the reference layout only carries group lengths)
+            const uint32_t y = x ^ 0x18181818u;
+            if (y) atomicMax(seq_len + (size_t)g * kGroupSeqs + sl + q, c * kChunkCols + ((39u - (uint32_t)__builtin_clz(y)) >> 3));
+            o[q] = dev_code(x & 0xffu) | dev_code((x >> 8) & 0xffu) << 8 | dev_code((x >> 16) & 0xffu) << 16 | dev_code(x >> 24) << 24;
+        }
+        *(uint4 *)(tiled + goff[g] + (size_t)(c * 128 + sl) * 4) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // blocks per group of the two tiling kernels: eight (chunk, sequence) dwords per thread for the longest group, at most 32
 static unsigned tile_slices(uint32_t max_cols)
 {
@@ -1393,7 +1439,10 @@ hipError_t launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *di
                          hipStream_t s)
 {
     if (dev_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(retile_kernel, dim3(dev_groups, tile_slices(max_cols)), dim3(256), 0, s, b, n, disp, vl_groups, vl, goff, gcols, tiled, seq_len);
+    if (vl % 4 == 0)
+        hipLaunchKernelGGL(retile4_kernel, dim3(dev_groups, tile_slices(max_cols / 4)), dim3(256), 0, s, b, n, disp, vl_groups, vl, goff, gcols, tiled, seq_len);
+    else
+        hipLaunchKernelGGL(retile_kernel, dim3(dev_groups, tile_slices(max_cols)), dim3(256), 0, s, b, n, disp, vl_groups, vl, goff, gcols, tiled, seq_len);
     return hipGetLastError();
 }
 

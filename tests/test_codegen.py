@@ -52,8 +52,8 @@ def test_register_classes(isa):
         if k["kernel"] == "sw_pipe_kernel" and k["growing_list"]:
             assert k["vgprs"] <= 160 and (k["vgprs"] <= 120 or k["rows_per_wave"] >= 24), k
         # the tiling kernels and the publisher run while pipeline waves fill the chip: they must fit what 4 x 120 registers leave of 512
-        if k["kernel"] in ("retile_kernel", "tile_sequences_kernel", "publish_items_kernel"):
+        if k["kernel"] in ("retile_kernel", "retile4_kernel", "tile_sequences_kernel", "publish_items_kernel"):
             assert k["vgprs"] <= 32 and k["scratch_bytes"] == 0, k
         if k["kernel"] == "sw_lane_kernel":
             assert k["vgprs"] <= 80, k
-    assert {"retile_kernel", "tile_sequences_kernel", "publish_items_kernel"} <= {k["kernel"] for k in isa}
+    assert {"retile_kernel", "retile4_kernel", "tile_sequences_kernel", "publish_items_kernel"} <= {k["kernel"] for k in isa}

@@ -388,6 +388,7 @@ struct SearchRun {
     SearchRun(swimm_hip_ctx *ctx, uint32_t b, uint32_t e) : c(ctx), qb(b), qe(e) {}
     ~SearchRun()
     {
+        if (wait_before_issue && c->up) { c->up->finish(true); (void)hipDeviceSynchronize(); }      // (an early return before the wait)
         if (!streaming) return;
         if (c->up) c->up->finish(true);          // (an early return: the chunks not yet copied stay where they are)
         if (one_list_launched && c->up && (c->up->failed || c->up->issued < up_order.size()))
@@ -399,6 +400,17 @@ struct SearchRun {
     {
         for (auto &m : stream_plans) for (auto &kv : m) { kv.second.main.release(); kv.second.tail.release(); }
         stream_plans.clear();
+    }
+    bool wait_before_issue = false;         // a database that is waited for as a whole (layout_ranges): the wait is still to come
+    int wait_for_the_database()             // every part handed to the device, the launch streams behind the last part's tiling kernel
+    {
+        if (wait_uploaded(up_order.size())) return 1;
+        const UploadPart &last = up_order.back();            // (the upload stream is in order)
+        for (hipStream_t st : {c->stream, c->stream_b, c->stream2, c->stream3}) HIP_TRY(hipStreamWaitEvent(st, last.ready, 0));
+        if (dbg) fprintf(stderr, "swimm_hip: host copies done %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
+        c->up->finish(false);
+        wait_before_issue = false;
+        return 0;
     }
     int wait_uploaded(size_t n)             // until the first n chunks of `up_order` are on their way
     {
@@ -717,11 +729,11 @@ int SearchRun::layout_ranges()
     // shapes -- cost 6 %; c5: 40 ms before 7.2 s).
     if (up_total <= 0.015 * dp_total) {
         if (dbg) fprintf(stderr, "swimm_hip: the database lands in %.1f ms, its alignment takes %.0f ms: waiting for it, then searching it as a resident one\n", up_total * 1e3, dp_total * 1e3);
-        if (wait_uploaded(np)) return 1;
-        const UploadPart &last = up_order[np - 1];              // (the upload stream is in order)
-        for (hipStream_t st : {c->stream, c->stream_b, c->stream2, c->stream3}) HIP_TRY(hipStreamWaitEvent(st, last.ready, 0));
-        if (dbg) fprintf(stderr, "swimm_hip: host copies done %.3f ms after the call began\n", (now_s() - t_begin) * 1e3);
-        c->up->finish(false);
+        // (.seq slabs carry their sequences' lengths: launch shapes, profiles and work lists are made while the database lands and the
+        // wait comes right before the first launch, issue(); the chunk layout's true lengths come from the re-tile kernel: wait now)
+        wait_before_issue = true;
+        for (const ChunkRec &r : c->chunks) wait_before_issue = wait_before_issue && (r.uploaded || r.lens_known);
+        if (!wait_before_issue && wait_for_the_database()) return 1;
         streaming = false;
         c->streaming_now = false;
         c->stream_tail.clear();
@@ -1227,6 +1239,7 @@ int SearchRun::issue()
         if (list_copy(c, c->d_qdesc.p, qd_host.data(), qd_host.size() * sizeof(QDesc)) ||
             list_copy(c, c->d_wave_out.p, wave_host.data(), wave_host.size() * sizeof(uint32_t)) || list_sync(c)) return 1;
     }
+    if (wait_before_issue && wait_for_the_database()) return 1;
     if (streaming && !one_list)          // the first range's work lists need its geometry only: ready before its bytes are
         for (uint32_t q = 0; q < qn; ++q) { DbPlan *dp = nullptr; if (plan_of(0, q, &dp)) return 1; }
     for (size_t ri = 0; ri < ranges.size(); ++ri) {

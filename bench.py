@@ -740,7 +740,7 @@ def main():
                 "per_rank_kernel_gcups": [c5["valu_roofline"]["kernel_only_gcups"]],
                 "hbm_frac": c5["roofline"]["frac"] if c5["roofline"] else None,
                 "rccl_ranks": 0, "topr_exchange": "none", "bit_exact": c5["bit_exact_vs_reference"] and c5["merged_top20_matches_full_vectors"],
-                "note": "N = 1 at a quarter of the database (at N > 1 the whole 7e9-residue database is sharded: --strong-scale 1); GCUPS does not depend on the scale from 10 % up (profiles/r04_bench_c5_full.json: the whole database on one GPU, 10 217 GCUPS)"}
+                "note": "N = 1 at a quarter of the database (at N > 1 the whole 7e9-residue database is sharded: --strong-scale 1); GCUPS does not depend on the scale from 10 % up (profiles/r04_bench_c5_full.json: the whole database on one GPU, 10 215 GCUPS)"}
         else:
             r2, ok2 = run_workload(env, args, "c5", args.strong_scale, args.secondary_steps, 1, 6.0, 0 if args.no_cold else 1, False)
             all_ok = all_ok and ok2

@@ -129,7 +129,7 @@ static void cpu_leg(const swimm_options *o, const swimm_queries *q, const char *
  * [device][query][top], indices global. */
 static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swimm_queries *q, const char *submat,
                     const uint16_t *lengths, const char *codes, uint64_t count, uint64_t first, unsigned long top,
-                    int32_t *part_s, int64_t *part_i, leg_stats *st)
+                    int32_t *part_s, int64_t *part_i, leg_stats *st, swimm_hip_ctx **keep_ctx)
 {
     const double tick = swimm_wtime();
     const int G = o->num_gpus;
@@ -174,7 +174,10 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
             api->last_stats(ctx, &g_kms[g], NULL, &g_prom[g], NULL);
             for (size_t i = 0; i < q->count * top; ++i) if (pi[i] >= 0) pi[i] += (int64_t)first;
         }
-        if (ctx) api->destroy(ctx);
+        /* (tearing a context down returns tens of GB to the driver -- about a second for the 7e9-residue database: the caller does
+         * it after the search's clock has stopped) */
+        if (ctx && keep_ctx) keep_ctx[g] = ctx;
+        else if (ctx) api->destroy(ctx);
         g_done[g] = 1;
     }
     for (int g = 0; g < G; ++g) if (gerr[g][0]) { printf("SWIMM: GPU %d: %s\n", g, gerr[g]); exit(5); }
@@ -513,7 +516,8 @@ int main(int argc, char **argv)
             if (!part_s || !part_i) { printf("SWIMM: An error occurred while allocating memory.\n"); exit(1); }
             for (size_t i = 0; i < (size_t)G * q.count * top; ++i) { part_s[i] = -1; part_i[i] = -1; }
             const double tick = swimm_wtime();   /* brackets transfers + kernels + merge, like MICsearch.c:51,350 */
-            gpu_leg(&api, &o, &q, submat, db.lengths, db.codes, db.count, 0, top, part_s, part_i, &gst);
+            swimm_hip_ctx **ctxs = (swimm_hip_ctx **)calloc((size_t)G, sizeof *ctxs);
+            gpu_leg(&api, &o, &q, submat, db.lengths, db.codes, db.count, 0, top, part_s, part_i, &gst, ctxs);
             /* host k-way merge of the per-device lists ([device][query][top]) */
             int32_t *ls = (int32_t *)malloc((size_t)G * top * sizeof(int32_t));
             int64_t *li = (int64_t *)malloc((size_t)G * top * sizeof(int64_t));
@@ -525,6 +529,10 @@ int main(int argc, char **argv)
                 swimm_topr_merge(ls, li, (uint32_t)G, (uint32_t)top, top_scores + i * top, top_idx + i * top);
             }
             workTime = swimm_wtime() - tick;
+            const double t_down = swimm_wtime();
+            for (int g = 0; ctxs && g < G; ++g) if (ctxs[g]) api.destroy(ctxs[g]);
+            if (getenv("SWIMM_DEBUG")) fprintf(stderr, "swimm: contexts torn down in %.3f s\n", swimm_wtime() - t_down);
+            free(ctxs);
             free(ls); free(li); free(part_s); free(part_i);
         }
     }

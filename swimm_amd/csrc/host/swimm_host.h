@@ -61,6 +61,9 @@ typedef struct {
     int max_title_length;
     uint16_t *lengths;      /* ascending */
     char *codes;            /* concatenated, 0..23 */
+    void *map_base;         /* the .seq file, mapped read-only: lengths and codes point into it (no copy of a 7 GB file; the
+                             * alphabet check touches its pages on all threads).  NULL: lengths / codes are malloc'ed */
+    uint64_t map_bytes;
 } swimm_db;
 int swimm_db_load(const char *prefix, swimm_db *out);
 void swimm_db_free(swimm_db *db);

